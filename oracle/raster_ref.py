@@ -1,0 +1,212 @@
+"""ORACLE (test infrastructure, NOT product code) -- ctypes front-end of raster_ref.c.
+
+CPU restatement of the third-party rasterizer pixelSplat calls at
+/root/reference/src/model/decoder/cuda_splatting.py:99-124 (module
+`diff_gaussian_rasterization`, unpinned, source absent).  PARITY UNPINNED: see the header
+of raster_ref_impl.inc and DESIGN.md.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_HERE, "libraster_ref.so")
+    srcs = [os.path.join(_HERE, f) for f in ("raster_ref.c", "raster_ref_impl.inc")]
+    stale = (not os.path.exists(path)) or any(
+        os.path.getmtime(s) > os.path.getmtime(path) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libraster_ref.so"],
+                              stdout=subprocess.DEVNULL)
+    return path
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ps_oracle_bin.restype = C.c_int64
+    return _LIB
+
+
+def _params_struct(real):
+    class P(C.Structure):
+        _fields_ = [
+            ("G", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+            ("sh_degree", C.c_int32), ("K", C.c_int32), ("use_sh", C.c_int32),
+            ("tanfovx", real), ("tanfovy", real),
+            ("near_cull", real), ("guard", real), ("lowpass", real), ("w_eps", real),
+            ("lambda_floor", real), ("alpha_max", real), ("alpha_min", real),
+            ("t_min", real), ("det2_eps", real),
+        ]
+    return P
+
+
+_P32 = _params_struct(C.c_float)
+_P64 = _params_struct(C.c_double)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class ForwardState:
+    """Everything the oracle computed for one view (every intermediate is exposed)."""
+    params: object
+    dtype: object
+    means: np.ndarray
+    cov6: np.ndarray
+    sh: np.ndarray | None
+    colors: np.ndarray | None
+    opacity: np.ndarray
+    view: np.ndarray
+    proj: np.ndarray
+    campos: np.ndarray
+    bg: np.ndarray
+    radii: np.ndarray
+    tiles_touched: np.ndarray
+    rect: np.ndarray
+    depth: np.ndarray
+    xy: np.ndarray
+    conic_opacity: np.ndarray
+    rgb: np.ndarray
+    clamped: np.ndarray
+    point_list: np.ndarray
+    keys: np.ndarray
+    ranges: np.ndarray
+    image: np.ndarray
+    final_T: np.ndarray
+    n_contrib: np.ndarray
+
+    @property
+    def num_rendered(self) -> int:
+        return int(self.point_list.shape[0])
+
+
+def forward(means, cov6, opacity, view, proj, campos, bg, H, W, tanfovx, tanfovy,
+            sh=None, colors=None, sh_degree=0, dtype=np.float32, threads: int | None = None,
+            **const_overrides) -> ForwardState:
+    """One view.  `view`/`proj` are the transposed 4x4 matrices of cuda_splatting.py:84-87
+    (flattened row-major of the transposed matrix, i.e. M[4*c + r])."""
+    L = lib()
+    f32 = dtype == np.float32
+    suf = "_f32" if f32 else "_f64"
+    P = (_P32 if f32 else _P64)()
+    getattr(L, "ps_oracle_defaults" + suf)(C.byref(P))
+    means = np.ascontiguousarray(means, dtype).reshape(-1, 3)
+    G = means.shape[0]
+    cov6 = np.ascontiguousarray(cov6, dtype).reshape(G, 6)
+    opacity = np.ascontiguousarray(opacity, dtype).reshape(G)
+    view = np.ascontiguousarray(view, dtype).reshape(16)
+    proj = np.ascontiguousarray(proj, dtype).reshape(16)
+    campos = np.ascontiguousarray(campos, dtype).reshape(3)
+    bg = np.ascontiguousarray(bg, dtype).reshape(3)
+    use_sh = sh is not None
+    if use_sh:
+        sh = np.ascontiguousarray(sh, dtype)
+        assert sh.ndim == 3 and sh.shape[0] == G and sh.shape[2] == 3
+        K = sh.shape[1]
+    else:
+        colors = np.ascontiguousarray(colors, dtype).reshape(G, 3)
+        K = 0
+    P.G, P.H, P.W, P.sh_degree, P.K, P.use_sh = G, H, W, sh_degree, K, int(use_sh)
+    P.tanfovx, P.tanfovy = float(tanfovx), float(tanfovy)
+    for k, v in const_overrides.items():
+        setattr(P, k, v)
+
+    radii = np.zeros(G, np.int32)
+    tiles = np.zeros(G, np.uint32)
+    rect = np.zeros((G, 4), np.int32)
+    depth = np.zeros(G, dtype)
+    xy = np.zeros((G, 2), dtype)
+    co = np.zeros((G, 4), dtype)
+    rgb = np.zeros((G, 3), dtype)
+    clamped = np.zeros((G, 3), np.uint8)
+    if threads is not None:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    getattr(L, "ps_oracle_preprocess" + suf)(
+        C.byref(P), _ptr(means), _ptr(cov6), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(view),
+        _ptr(proj), _ptr(campos), _ptr(radii), _ptr(tiles), _ptr(rect), _ptr(depth), _ptr(xy),
+        _ptr(co), _ptr(rgb), _ptr(clamped))
+
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    D = int(tiles.astype(np.int64).sum())
+    plist = np.zeros(max(D, 1), np.uint32)
+    keys = np.zeros(max(D, 1), np.uint64)
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    depth32 = np.ascontiguousarray(depth, np.float32)
+    D2 = L.ps_oracle_bin(C.c_int32(G), C.c_int32(H), C.c_int32(W), _ptr(radii), _ptr(rect),
+                         _ptr(depth32), _ptr(plist), _ptr(keys), _ptr(ranges))
+    assert D2 == D
+    plist, keys = plist[:D], keys[:D]
+
+    image = np.zeros((3, H, W), dtype)
+    final_T = np.zeros(H * W, dtype)
+    n_contrib = np.zeros(H * W, np.uint32)
+    pl = plist if D else np.zeros(1, np.uint32)
+    getattr(L, "ps_oracle_blend_forward" + suf)(
+        C.byref(P), _ptr(ranges), _ptr(pl), _ptr(xy), _ptr(co), _ptr(rgb), _ptr(bg),
+        _ptr(image), _ptr(final_T), _ptr(n_contrib))
+    return ForwardState(P, dtype, means, cov6, sh, colors, opacity, view, proj, campos, bg,
+                        radii, tiles, rect, depth, xy, co, rgb, clamped, plist, keys, ranges,
+                        image, final_T, n_contrib)
+
+
+def backward(st: ForwardState, dL_dimage):
+    """Returns dict(means3D, means2D, cov6, sh|colors, opacity) -- the five gradients the
+    reference's autograd needs (SURVEY.md section 8b 'Gradients required')."""
+    L = lib()
+    dtype = st.dtype
+    suf = "_f32" if dtype == np.float32 else "_f64"
+    P = st.params
+    G = P.G
+    g = np.ascontiguousarray(dL_dimage, dtype).reshape(3, P.H, P.W)
+    dxy = np.zeros((G, 2), dtype)
+    dconic = np.zeros((G, 3), dtype)
+    dop = np.zeros(G, dtype)
+    drgb = np.zeros((G, 3), dtype)
+    pl = st.point_list if st.num_rendered else np.zeros(1, np.uint32)
+    getattr(L, "ps_oracle_blend_backward" + suf)(
+        C.byref(P), _ptr(st.ranges), _ptr(pl), _ptr(st.xy), _ptr(st.conic_opacity), _ptr(st.rgb),
+        _ptr(st.bg), _ptr(st.final_T), _ptr(st.n_contrib), _ptr(g), _ptr(dxy), _ptr(dconic),
+        _ptr(dop), _ptr(drgb))
+    dmeans = np.zeros((G, 3), dtype)
+    dcov = np.zeros((G, 6), dtype)
+    dsh = np.zeros_like(st.sh) if st.sh is not None else None
+    getattr(L, "ps_oracle_preprocess_backward" + suf)(
+        C.byref(P), _ptr(st.means), _ptr(st.cov6), _ptr(st.sh), _ptr(st.view), _ptr(st.proj),
+        _ptr(st.campos), _ptr(st.radii), _ptr(st.clamped), _ptr(dxy), _ptr(dconic), _ptr(drgb),
+        _ptr(dmeans), _ptr(dcov), _ptr(dsh))
+    means2d = np.zeros((G, 3), dtype)
+    means2d[:, :2] = dxy
+    out = dict(means3D=dmeans, means2D=means2d, cov6=dcov, opacity=dop,
+               xy=dxy, conic=dconic, rgb=drgb)
+    if st.sh is not None:
+        out["sh"] = dsh
+    else:
+        out["colors"] = drgb.copy()
+    return out
+
+
+def sh_basis(deg: int, dirs: np.ndarray) -> np.ndarray:
+    """[N,3] unit directions -> [N,(deg+1)^2] basis values (fp64)."""
+    L = lib()
+    dirs = np.ascontiguousarray(dirs, np.float64).reshape(-1, 3)
+    n = (deg + 1) ** 2
+    out = np.zeros((dirs.shape[0], 25), np.float64)
+    L.ps_oracle_sh_basis_f64.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    for i, (x, y, z) in enumerate(dirs):
+        L.ps_oracle_sh_basis_f64(deg, x, y, z, out[i].ctypes.data_as(C.c_void_p))
+    return out[:, :n]

@@ -1,0 +1,150 @@
+"""Pins the (B) oracle -- there is no reference golden vector for the rasterizer
+("parity unpinned"), so the restatement is pinned by the invariants
+the survey lists: SH orthonormality, analytic footprint, blend bounds, fp64 central
+differences of its own forward, and order/translation invariances."""
+import numpy as np
+import pytest
+
+from oracle import raster_ref as R
+from tests.cases import small_scene
+
+
+def _fib_sphere(n):
+    i = np.arange(n) + 0.5
+    phi = np.arccos(1 - 2 * i / n)
+    th = np.pi * (1 + 5 ** 0.5) * i
+    return np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], -1)
+
+
+def test_sh_basis_orthonormal():
+    # 25 real SH functions, degree <= 4: (4 pi / N) sum_i Y_a Y_b = delta_ab
+    d = _fib_sphere(20000)
+    y = R.sh_basis(4, d)
+    gram = 4 * np.pi / d.shape[0] * y.T @ y
+    assert np.abs(gram - np.eye(25)).max() < 2e-3
+
+
+def _single(o=0.8, sigma=0.05, z=3.0, hw=(64, 64), dtype=np.float64, bg=(0, 0, 0)):
+    sc = small_scene(1, hw, dtype=dtype, sh_degree=0)
+    sc["means"][:] = [0.1, 0.0, z]  # on the optical axis of a camera at x = 0.1
+    s2 = sigma ** 2
+    sc["cov6"][:] = [s2, 0, 0, s2, 0, s2]
+    sc["opacity"][:] = o
+    sc["sh"][:] = (1.0 - 0.5) / 0.28209479177387814  # colour exactly 1
+    sc["bg"][:] = bg
+    return sc
+
+
+def test_single_gaussian_footprint():
+    sc = _single()
+    st = R.forward(dtype=np.float64, **sc)
+    h, w = sc["H"], sc["W"]
+    fx = w / (2 * sc["tanfovx"])
+    var = (fx * 0.05 / 3.0) ** 2 + 0.3  # projected variance + low-pass
+    px, py = st.xy[0]
+    assert abs(px - (w - 1) / 2) < 1e-6 and abs(py - (h - 1) / 2) < 1e-6  # fp32 matrices
+    yy, xx = np.mgrid[0:h, 0:w]
+    alpha = np.minimum(0.99, 0.8 * np.exp(-0.5 * ((xx - px) ** 2 + (yy - py) ** 2) / var))
+    alpha[alpha < 1 / 255] = 0
+    # restrict to the tile rect the Gaussian was binned to
+    r = st.rect[0]
+    mask = np.zeros((h, w), bool)
+    mask[r[1] * 16:r[3] * 16, r[0] * 16:r[2] * 16] = True
+    expect = np.where(mask, alpha, 0)
+    assert np.abs(st.image[0] - expect).max() < 1e-6
+    assert st.radii[0] == int(np.ceil(3 * np.sqrt(var)))
+
+
+def test_background_and_bounds():
+    sc = small_scene(64, (48, 40), seed=3)
+    st = R.forward(dtype=np.float64, **sc)
+    # sum alpha-blend weights <= 1: image - T*bg >= 0 and T in [0,1]
+    assert st.final_T.min() >= 0 and st.final_T.max() <= 1
+    # a pixel nobody touched shows the background
+    untouched = st.n_contrib.reshape(48, 40) == 0
+    ft = st.final_T.reshape(48, 40)
+    assert np.all(ft[untouched] == 1.0)
+    for c in range(3):
+        assert np.allclose(st.image[c][untouched], sc["bg"][c])
+
+
+def test_culls():
+    sc = small_scene(8, (32, 32), seed=1)
+    sc["means"][0, 2] = 0.1      # behind near-cull plane (z_view <= 0.2)
+    sc["means"][1, 0] = 50.0     # far outside the frustum -> empty rect
+    st = R.forward(dtype=np.float64, **sc)
+    assert st.radii[0] == 0 and st.tiles_touched[0] == 0
+    assert st.radii[1] == 0 or st.tiles_touched[1] == 0
+    g = R.backward(st, np.ones((3, 32, 32)))
+    assert np.all(g["means3D"][0] == 0) and np.all(g["sh"][0] == 0) and g["opacity"][0] == 0
+
+
+def test_permutation_invariance():
+    sc = small_scene(64, (32, 32), seed=5, dtype=np.float32)
+    st = R.forward(dtype=np.float32, **sc)
+    perm = np.random.default_rng(0).permutation(64)
+    sc2 = dict(sc)
+    for k in ("means", "cov6", "opacity", "sh"):
+        sc2[k] = sc[k][perm]
+    st2 = R.forward(dtype=np.float32, **sc2)
+    # same per-tile depth order (no depth ties in this scene) -> identical image bits
+    assert np.array_equal(st.image, st2.image)
+    assert np.array_equal(perm[st2.point_list], st.point_list)
+
+
+def test_bin_ranges_and_sortedness():
+    sc = small_scene(200, (64, 48), seed=7, dtype=np.float32)
+    st = R.forward(dtype=np.float32, **sc)
+    assert st.num_rendered == st.tiles_touched.sum()
+    assert np.all(np.diff(st.keys.astype(np.uint64)) >= 0)
+    gx = 3
+    for t, (a, b) in enumerate(st.ranges):
+        ids = st.point_list[a:b]
+        tx, ty = t % gx, t // gx
+        r = st.rect[ids]
+        assert np.all((r[:, 0] <= tx) & (tx < r[:, 2]) & (r[:, 1] <= ty) & (ty < r[:, 3]))
+        d = st.depth[ids]
+        assert np.all(np.diff(d) >= 0)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gradients_vs_central_differences(seed):
+    """fp64 central differences of the oracle's own forward.  Inputs are chosen away from
+    the two documented non-differentiable quirks (alpha_max clamp pass-through and the
+    frustum-guard zeroing), so the analytic backward must agree."""
+    sc = small_scene(24, (32, 32), seed=seed, opacity_hi=0.5)
+    st = R.forward(dtype=np.float64, **sc)
+    rng = np.random.default_rng(seed + 10)
+    wimg = rng.normal(size=(3, 32, 32))
+    grads = R.backward(st, wimg)
+
+    def loss(**over):
+        s = dict(sc)
+        s.update(over)
+        return float((R.forward(dtype=np.float64, **s).image * wimg).sum())
+
+    eps = 1e-6
+    checks = [("means", "means3D"), ("cov6", "cov6"), ("opacity", "opacity"), ("sh", "sh")]
+    worst = 0.0
+    for name, gname in checks:
+        base = sc[name]
+        flat_idx = rng.choice(base.size, size=min(40, base.size), replace=False)
+        for fi in flat_idx:
+            idx = np.unravel_index(fi, base.shape)
+            p = base.copy(); p[idx] += eps
+            m = base.copy(); m[idx] -= eps
+            fd = (loss(**{name: p}) - loss(**{name: m})) / (2 * eps)
+            an = grads[gname][idx]
+            err = abs(fd - an) / max(1e-4, abs(fd), abs(an))
+            worst = max(worst, err)
+            assert err < 2e-4, (name, idx, fd, an)
+    assert worst < 2e-4
+
+
+def test_means2d_gradient_is_ndc_scaled_pixel_gradient():
+    # dL/dmeans2D.x = dL/dpx * (W/2): shift every projected centre by one pixel via the
+    # principal point is not expressible at this API, so check against dL/dxy directly.
+    sc = small_scene(16, (32, 32), seed=2)
+    st = R.forward(dtype=np.float64, **sc)
+    g = R.backward(st, np.ones((3, 32, 32)))
+    assert np.array_equal(g["means2D"][:, :2], g["xy"]) and np.all(g["means2D"][:, 2] == 0)
