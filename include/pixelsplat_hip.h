@@ -1,0 +1,163 @@
+/*
+ * pixelsplat_hip.h -- C ABI of libpixelsplat_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of pixelSplat's hot path.  Plain pointers and sizes only: every
+ * buffer is DEVICE memory owned by the caller (PyTorch's caching allocator in practice),
+ * `stream` is a hipStream_t passed as void*, the library keeps no state between calls,
+ * never throws / aborts / synchronises the device, and returns 0 or a negative PsStatus.
+ *
+ * (B) rasterizer.  Replaces what the reference reaches through the third-party module
+ *     `diff_gaussian_rasterization` (GaussianRasterizer.forward / autograd backward):
+ *       /root/reference/src/model/decoder/cuda_splatting.py:5-8     import
+ *       /root/reference/src/model/decoder/cuda_splatting.py:99-124  per-view call (render_cuda)
+ *       /root/reference/src/model/decoder/cuda_splatting.py:192-217 per-view call (orthographic)
+ *     and, in its batched form (n_views > 1, views_per_scene > 1, PS_SH_G3K / PS_COV_33,
+ *     per-view scene_scale), the whole body of
+ *       /root/reference/src/model/decoder/cuda_splatting.py:47-127  render_cuda
+ *       /root/reference/src/model/decoder/decoder_splatting_cuda.py:46-57 (no v-fold repeat)
+ *
+ * (A) epipolar sampler + attention: ps_epipolar_* (see below; added as that path lands).
+ */
+#ifndef PIXELSPLAT_HIP_H
+#define PIXELSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PsStatus {
+  PS_OK = 0,
+  PS_ERR_BAD_ARG = -1,     /* null pointer / inconsistent descriptor            */
+  PS_ERR_WORKSPACE = -2,   /* state/temp buffer smaller than ps_raster_*_bytes  */
+  PS_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after a launch    */
+  PS_ERR_UNSUPPORTED = -4  /* e.g. sh_degree > 4, image wider than 65535 tiles  */
+} PsStatus;
+
+/* layout selectors */
+#define PS_SH_GK3 0  /* sh[G][K][3]  -- the rasterizer boundary (cuda_splatting.py:75)        */
+#define PS_SH_G3K 1  /* sh[G][3][K]  -- reference `Gaussians.harmonics` (src/model/types.py:11) */
+#define PS_COV_6 0   /* cov[G][6] = xx,xy,xz,yy,yz,zz  (cuda_splatting.py:115,123)            */
+#define PS_COV_33 1  /* cov[G][3][3] -- reference `Gaussians.covariances`; upper triangle read,
+                        gradient written to the upper triangle (lower = 0), as autograd of
+                        cov[:, triu_row, triu_col] would                                        */
+
+/* per-view parameter block: PS_VIEW_STRIDE floats, device memory, one per view.
+ * Matrices are the TRANSPOSED (row-vector) 4x4s of cuda_splatting.py:84-87, i.e. element
+ * [4*c + r] is row r / column c of the column-vector matrix. */
+#define PS_VIEW_STRIDE 48
+#define PS_VIEW_VIEWMATRIX 0   /* 16: world -> camera                                */
+#define PS_VIEW_PROJMATRIX 16  /* 16: world -> clip (view @ projection)              */
+#define PS_VIEW_CAMPOS 32      /*  3: camera position (after scene_scale)            */
+#define PS_VIEW_TANFOVX 35
+#define PS_VIEW_TANFOVY 36
+#define PS_VIEW_BG 37          /*  3: background colour                              */
+#define PS_VIEW_SCALE 40       /*  1: scene_scale s: means*s, cov*s^2 on load (the
+                                      scale-invariant renorm of cuda_splatting.py:64-71;
+                                      1.0 for the plain per-view boundary)            */
+
+typedef struct PsRasterDesc {
+  int32_t n_scenes;        /* S: independent Gaussian sets                           */
+  int32_t views_per_scene; /* views rendered from each set; view v uses scene v / views_per_scene */
+  int32_t n_gaussians;     /* G per scene                                            */
+  int32_t height, width;
+  int32_t sh_degree;       /* active degree 0..4                                     */
+  int32_t sh_coeffs;       /* K stored per channel (>= (deg+1)^2); 0 => colors_precomp */
+  int32_t sh_layout;       /* PS_SH_*                                                */
+  int32_t cov_layout;      /* PS_COV_*                                               */
+  int32_t reserved;
+  /* algorithm constants; ps_raster_default_desc fills them */
+  float near_cull;    /* 0.2   */
+  float guard;        /* 1.3   */
+  float lowpass;      /* 0.3   */
+  float w_eps;        /* 1e-7  */
+  float lambda_floor; /* 0.1   */
+  float alpha_max;    /* 0.99  */
+  float alpha_min;    /* 1/255 */
+  float t_min;        /* 1e-4  */
+  float det2_eps;     /* 1e-7  */
+} PsRasterDesc;
+
+/* byte offsets of the arrays inside the `state` buffer (for tests / debugging).
+ * V = n_scenes*views_per_scene, N = V*G, P = H*W, T = tiles per view. */
+typedef struct PsRasterStateLayout {
+  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,r,g | b,depth,radius(i32),clamp bits */
+  size_t rects;       /* uint16[N][4]: tile rect xmin,ymin,xmax,ymax                   */
+  size_t sorted_idx;  /* uint32[N]: per view, Gaussian ids in (depth, id) order; first n_vis valid */
+  size_t sorted_rect; /* uint16[N][4]: rects permuted into sorted order                */
+  size_t n_vis;       /* uint32[V]                                                     */
+  size_t final_T;     /* float[V][P]                                                   */
+  size_t n_contrib;   /* uint32[V][P]: 1-based index (within the tile's list) of the last contributor */
+  size_t tile_end;    /* uint32[V][T][2]: (max n_contrib in tile, sorted position + 1 of that entry) */
+  size_t total;
+} PsRasterStateLayout;
+
+void ps_raster_default_desc(PsRasterDesc* desc);
+size_t ps_raster_state_bytes(const PsRasterDesc* desc); /* lives from forward to backward */
+size_t ps_raster_temp_bytes(const PsRasterDesc* desc);  /* scratch of one call            */
+int ps_raster_state_layout(const PsRasterDesc* desc, PsRasterStateLayout* out);
+
+/* Forward.  Replaces GaussianRasterizer.forward (cuda_splatting.py:117-124).
+ *   means      float[S][G][3]
+ *   cov        float[S][G][6] or [S][G][3][3]   (cov_layout)
+ *   sh         float[S][G][K][3] or [S][G][3][K] (sh_layout), or NULL
+ *   colors     float[V][G][3] per-VIEW precomputed colours, or NULL (exactly one of sh/colors)
+ *   opacity    float[S][G]
+ *   view_params float[V][PS_VIEW_STRIDE]
+ *   out_color  float[V][3][H][W]      out_radii int32[V][G]
+ */
+int ps_raster_forward(const PsRasterDesc* desc, const float* means, const float* cov,
+                      const float* sh, const float* colors, const float* opacity,
+                      const float* view_params, float* out_color, int32_t* out_radii,
+                      void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                      void* stream);
+
+/* Backward.  Replaces _RasterizeGaussians.backward of the external module.
+ *   radii       int32[V][G]  (the forward's out_radii)
+ *   dL_dcolor   float[V][3][H][W]
+ *   dL_dmeans   float[S][G][3]           dL_dcov  as cov layout
+ *   dL_dsh      as sh layout, or NULL    dL_dcolors float[V][G][3], or NULL
+ *   dL_dopacity float[S][G]
+ *   dL_dmeans2D float[V][G][3] (NDC-scaled screen-space gradient, z = 0), may be NULL
+ * Gradients are summed over the views of a scene (what autograd's `repeat` backward does,
+ * decoder_splatting_cuda.py:53-56) and include the scene_scale chain rule.
+ */
+int ps_raster_backward(const PsRasterDesc* desc, const float* means, const float* cov,
+                       const float* sh, const float* colors, const float* opacity,
+                       const float* view_params, const int32_t* radii, const float* dL_dcolor,
+                       const void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                       float* dL_dmeans,
+                       float* dL_dcov, float* dL_dsh, float* dL_dcolors, float* dL_dopacity,
+                       float* dL_dmeans2D, void* stream);
+
+/* Debug/parity export of the per-tile bins the forward pass walked implicitly:
+ *   tile_counts uint32[V][T]   (number of Gaussians whose rect covers the tile)
+ *   point_list  uint32[capacity] concatenated per-(view,tile) lists of Gaussian ids in
+ *               blend order, tile t of view v starting at the exclusive prefix sum of
+ *               tile_counts; written only if point_list != NULL (call once with NULL to
+ *               size it).  Bit-exact counterpart of the reference's sorted point list +
+ *               tile ranges.
+ */
+int ps_raster_export_bins(const PsRasterDesc* desc, const void* state, size_t state_bytes,
+                          uint32_t* tile_counts, const uint32_t* tile_offsets,
+                          uint32_t* point_list, size_t capacity, void* stream);
+
+/* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
+ * library).  When enabled every kernel group the library launches is bracketed by hipEvents
+ * on the caller's stream; ps_profile_collect synchronises those events, ADDS the elapsed
+ * milliseconds / launch counts per group into the caller's arrays (length
+ * ps_profile_group_count()) and clears the pending list. */
+int ps_profile_enable(int on);
+int ps_profile_group_count(void);
+const char* ps_profile_group_name(int group);
+int ps_profile_collect(double* total_ms, int64_t* launches);
+
+const char* ps_status_string(int status);
+const char* ps_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXELSPLAT_HIP_H */

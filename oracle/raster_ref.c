@@ -13,6 +13,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+static int ps_oracle_par_bwd = 0;
+void ps_oracle_parallel_backward(int on) { ps_oracle_par_bwd = on; }
+#define PS_ATOMIC _Pragma("omp atomic")
+
 #define REAL float
 #define SUF _f32
 #include "raster_ref_impl.inc"

@@ -200,6 +200,11 @@ def backward(st: ForwardState, dL_dimage):
     return out
 
 
+def parallel_backward(on: bool) -> None:
+    """CPU-baseline timing only: spread the blend backward over cores (sums reorder)."""
+    lib().ps_oracle_parallel_backward(C.c_int(int(on)))
+
+
 def sh_basis(deg: int, dirs: np.ndarray) -> np.ndarray:
     """[N,3] unit directions -> [N,(deg+1)^2] basis values (fp64)."""
     L = lib()

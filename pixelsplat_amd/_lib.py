@@ -1,0 +1,107 @@
+"""ctypes binding of libpixelsplat_hip.so (the C ABI of include/pixelsplat_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent
+this raises -- there is no eager/PyTorch or CPU path behind these ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpixelsplat_hip.so")
+
+PS_SH_GK3, PS_SH_G3K = 0, 1
+PS_COV_6, PS_COV_33 = 0, 1
+PS_VIEW_STRIDE = 48
+PS_VIEW_VIEWMATRIX, PS_VIEW_PROJMATRIX, PS_VIEW_CAMPOS = 0, 16, 32
+PS_VIEW_TANFOVX, PS_VIEW_TANFOVY, PS_VIEW_BG, PS_VIEW_SCALE = 35, 36, 37, 40
+
+
+class PsRasterDesc(C.Structure):
+    _fields_ = [
+        ("n_scenes", C.c_int32), ("views_per_scene", C.c_int32), ("n_gaussians", C.c_int32),
+        ("height", C.c_int32), ("width", C.c_int32), ("sh_degree", C.c_int32),
+        ("sh_coeffs", C.c_int32), ("sh_layout", C.c_int32), ("cov_layout", C.c_int32),
+        ("reserved", C.c_int32),
+        ("near_cull", C.c_float), ("guard", C.c_float), ("lowpass", C.c_float),
+        ("w_eps", C.c_float), ("lambda_floor", C.c_float), ("alpha_max", C.c_float),
+        ("alpha_min", C.c_float), ("t_min", C.c_float), ("det2_eps", C.c_float),
+    ]
+
+
+class PsRasterStateLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "records", "rects", "sorted_idx", "sorted_rect", "n_vis", "final_T", "n_contrib",
+        "tile_end", "total")]
+
+
+# every symbol include/pixelsplat_hip.h declares
+EXPORTS = [
+    "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
+    "ps_raster_state_layout", "ps_raster_forward", "ps_raster_backward",
+    "ps_raster_export_bins", "ps_status_string", "ps_build_info",
+    "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
+]
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library (cached).  Raises HipExtensionMissing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python -m pixelsplat_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no non-HIP fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipExtensionMissing(f"{LIB_PATH} does not export {name}")
+    vp = C.c_void_p
+    lib.ps_raster_default_desc.argtypes = [C.POINTER(PsRasterDesc)]
+    lib.ps_raster_default_desc.restype = None
+    lib.ps_raster_state_bytes.argtypes = [C.POINTER(PsRasterDesc)]
+    lib.ps_raster_state_bytes.restype = C.c_size_t
+    lib.ps_raster_temp_bytes.argtypes = [C.POINTER(PsRasterDesc)]
+    lib.ps_raster_temp_bytes.restype = C.c_size_t
+    lib.ps_raster_state_layout.argtypes = [C.POINTER(PsRasterDesc), C.POINTER(PsRasterStateLayout)]
+    lib.ps_raster_state_layout.restype = C.c_int
+    lib.ps_raster_forward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [
+        vp, C.c_size_t, vp, C.c_size_t, vp]
+    lib.ps_raster_forward.restype = C.c_int
+    lib.ps_raster_backward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [
+        vp, C.c_size_t, vp, C.c_size_t] + [vp] * 6 + [vp]
+    lib.ps_raster_backward.restype = C.c_int
+    lib.ps_raster_export_bins.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t, vp, vp, vp,
+                                          C.c_size_t, vp]
+    lib.ps_raster_export_bins.restype = C.c_int
+    lib.ps_profile_enable.argtypes = [C.c_int]
+    lib.ps_profile_group_count.restype = C.c_int
+    lib.ps_profile_group_name.argtypes = [C.c_int]
+    lib.ps_profile_group_name.restype = C.c_char_p
+    lib.ps_profile_collect.argtypes = [vp, vp]
+    lib.ps_status_string.argtypes = [C.c_int]
+    lib.ps_status_string.restype = C.c_char_p
+    lib.ps_build_info.argtypes = []
+    lib.ps_build_info.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().ps_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (PsStatus {status})")
+
+
+def default_desc() -> PsRasterDesc:
+    d = PsRasterDesc()
+    load().ps_raster_default_desc(C.byref(d))
+    return d

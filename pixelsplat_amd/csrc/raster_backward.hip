@@ -1,0 +1,243 @@
+// Preprocess backward: screen-space gradients (dxy in NDC units, dconic, dopacity, drgb
+// accumulated per (view, Gaussian) by the tile backward) -> dL/d{means, cov, SH|colors,
+// opacity}.  One thread per scene Gaussian, looping over the scene's views and summing in
+// registers: each output is written once, without atomics, and the v-fold `repeat`
+// backward of decoder_splatting_cuda.py:53-56 never materialises.
+//
+// Semantics: SURVEY.md Appendix A.4 (upstream quirks kept: the 2-D mean gradient is in NDC
+// units, the frustum-guard clamp zeroes d/dt.x, d/dt.y, the off-diagonal conic gradient is
+// stored once).  Replaces computeCov2D/preprocess backward of the external rasterizer
+// reached from /root/reference/src/model/decoder/cuda_splatting.py:117-124 via autograd.
+#include "raster_common.h"
+#include "sh_math.h"
+
+namespace ps {
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
+                           const float* __restrict__ cov, const float* __restrict__ sh,
+                           const float* __restrict__ view_params,
+                           const float* __restrict__ records, const int32_t* __restrict__ radii,
+                           const float* __restrict__ grad2d, float* __restrict__ dL_dmeans,
+                           float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
+                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                           float* __restrict__ dL_dmeans2D) {
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  const int G = d.n_gaussians, vps = d.views_per_scene, H = d.height, W = d.width;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (g >= G) return;
+  const size_t sg = (size_t)s * G + g;
+  const int K = d.sh_coeffs;
+  const bool use_sh = sh != nullptr;
+
+  float m0[3], c6[6];
+  {
+    const float* mp = means + sg * 3;
+    m0[0] = mp[0]; m0[1] = mp[1]; m0[2] = mp[2];
+    if (d.cov_layout == PS_COV_6) {
+      const float* cp = cov + sg * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = cp[k];
+    } else {
+      const float* cp = cov + sg * 9;
+      c6[0] = cp[0]; c6[1] = cp[1]; c6[2] = cp[2]; c6[3] = cp[4]; c6[4] = cp[5]; c6[5] = cp[8];
+    }
+  }
+  float shc[NB * 3], dsh[NB * 3];
+  bool sh_loaded = false;
+#pragma unroll
+  for (int i = 0; i < NB * 3; ++i) dsh[i] = 0.f;
+  float gm[3] = {0.f, 0.f, 0.f}, gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f;
+
+  for (int j = 0; j < vps; ++j) {
+    const int v = s * vps + j;
+    const size_t vg = (size_t)v * G + g;
+    const bool vis = radii[vg] > 0;
+    if (dL_dmeans2D) {
+      float* o = dL_dmeans2D + vg * 3;
+      o[0] = vis ? grad2d[vg * kGradFloats + 0] : 0.f;
+      o[1] = vis ? grad2d[vg * kGradFloats + 1] : 0.f;
+      o[2] = 0.f;
+    }
+    if (!use_sh && dL_dcolors) {
+      float* o = dL_dcolors + vg * 3;
+      o[0] = vis ? grad2d[vg * kGradFloats + 6] : 0.f;
+      o[1] = vis ? grad2d[vg * kGradFloats + 7] : 0.f;
+      o[2] = vis ? grad2d[vg * kGradFloats + 8] : 0.f;
+    }
+    if (!vis) continue;
+    const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
+    const float* V = vp + PS_VIEW_VIEWMATRIX;
+    const float* PV = vp + PS_VIEW_PROJMATRIX;
+    const float tanfovx = vp[PS_VIEW_TANFOVX], tanfovy = vp[PS_VIEW_TANFOVY];
+    const float scale = vp[PS_VIEW_SCALE], scale2 = scale * scale;
+    const float* gr = grad2d + vg * kGradFloats;
+    const float gx2 = gr[0], gy2 = gr[1], gcx = gr[2], gcy = gr[3], gcz = gr[4];
+    const float g_op = gr[5], gr0 = gr[6], gr1 = gr[7], gr2 = gr[8];
+    const uint32_t clamp_bits = __float_as_uint(records[vg * kRecFloats + 11]);
+
+    const float mx = m0[0] * scale, my = m0[1] * scale, mz = m0[2] * scale;
+    const float tvx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+    const float tvy = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+    const float tvz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    const float limx = d.guard * tanfovx, limy = d.guard * tanfovy;
+    const float txtz = tvx / tvz, tytz = tvy / tvz;
+    const float tx = fminf(limx, fmaxf(-limx, txtz)) * tvz;
+    const float ty = fminf(limy, fmaxf(-limy, tytz)) * tvz;
+    const float xgm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float ygm = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float J00 = fx / tvz, J02 = -(fx * tx) / (tvz * tvz);
+    const float J11 = fy / tvz, J12 = -(fy * ty) / (tvz * tvz);
+    const float R00 = V[0], R01 = V[4], R02 = V[8], R10 = V[1], R11 = V[5], R12 = V[9],
+                R20 = V[2], R21 = V[6], R22 = V[10];
+    const float M00 = J00 * R00 + J02 * R20, M01 = J00 * R01 + J02 * R21,
+                M02 = J00 * R02 + J02 * R22;
+    const float M10 = J11 * R10 + J12 * R20, M11 = J11 * R11 + J12 * R21,
+                M12 = J11 * R12 + J12 * R22;
+    const float S00 = c6[0] * scale2, S01 = c6[1] * scale2, S02 = c6[2] * scale2,
+                S11 = c6[3] * scale2, S12 = c6[4] * scale2, S22 = c6[5] * scale2;
+    const float a0 = S00 * M00 + S01 * M01 + S02 * M02;
+    const float a1 = S01 * M00 + S11 * M01 + S12 * M02;
+    const float a2 = S02 * M00 + S12 * M01 + S22 * M02;
+    const float b0 = S00 * M10 + S01 * M11 + S02 * M12;
+    const float b1 = S01 * M10 + S11 * M11 + S12 * M12;
+    const float b2 = S02 * M10 + S12 * M11 + S22 * M12;
+    const float a = (M00 * a0 + M01 * a1 + M02 * a2) + d.lowpass;
+    const float b = M10 * a0 + M11 * a1 + M12 * a2;
+    const float c = (M10 * b0 + M11 * b1 + M12 * b2) + d.lowpass;
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / (denom * denom + d.det2_eps);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    if (denom2inv != 0.f) {
+      dL_da = denom2inv * (-c * c * gcx + 2.f * b * c * gcy + (denom - a * c) * gcz);
+      dL_dc = denom2inv * (-a * a * gcz + 2.f * a * b * gcy + (denom - a * c) * gcx);
+      dL_db = denom2inv * 2.f * (b * c * gcx - (denom + 2.f * b * b) * gcy + a * b * gcz);
+      gc[0] += scale2 * (M00 * M00 * dL_da + M00 * M10 * dL_db + M10 * M10 * dL_dc);
+      gc[3] += scale2 * (M01 * M01 * dL_da + M01 * M11 * dL_db + M11 * M11 * dL_dc);
+      gc[5] += scale2 * (M02 * M02 * dL_da + M02 * M12 * dL_db + M12 * M12 * dL_dc);
+      gc[1] += scale2 * (2.f * M00 * M01 * dL_da + (M00 * M11 + M01 * M10) * dL_db +
+                         2.f * M10 * M11 * dL_dc);
+      gc[2] += scale2 * (2.f * M00 * M02 * dL_da + (M00 * M12 + M02 * M10) * dL_db +
+                         2.f * M10 * M12 * dL_dc);
+      gc[4] += scale2 * (2.f * M01 * M02 * dL_da + (M01 * M12 + M02 * M11) * dL_db +
+                         2.f * M11 * M12 * dL_dc);
+    }
+    const float dM00 = 2.f * a0 * dL_da + b0 * dL_db, dM01 = 2.f * a1 * dL_da + b1 * dL_db,
+                dM02 = 2.f * a2 * dL_da + b2 * dL_db;
+    const float dM10 = 2.f * b0 * dL_dc + a0 * dL_db, dM11 = 2.f * b1 * dL_dc + a1 * dL_db,
+                dM12 = 2.f * b2 * dL_dc + a2 * dL_db;
+    const float dJ00 = R00 * dM00 + R01 * dM01 + R02 * dM02;
+    const float dJ02 = R20 * dM00 + R21 * dM01 + R22 * dM02;
+    const float dJ11 = R10 * dM10 + R11 * dM11 + R12 * dM12;
+    const float dJ12 = R20 * dM10 + R21 * dM11 + R22 * dM12;
+    const float tz = 1.0f / tvz, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = xgm * -fx * tz2 * dJ02;
+    const float dty = ygm * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * tx) * tz3 * dJ02 +
+                      (2.f * fy * ty) * tz3 * dJ12;
+    float gmx = R00 * dtx + R10 * dty + R20 * dtz;
+    float gmy = R01 * dtx + R11 * dty + R21 * dtz;
+    float gmz = R02 * dtx + R12 * dty + R22 * dtz;
+    {
+      const float hx = PV[0] * mx + PV[4] * my + PV[8] * mz + PV[12];
+      const float hy = PV[1] * mx + PV[5] * my + PV[9] * mz + PV[13];
+      const float hw = PV[3] * mx + PV[7] * my + PV[11] * mz + PV[15];
+      const float m_w = 1.0f / (hw + d.w_eps);
+      const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+      gmx += (PV[0] * m_w - PV[3] * mul1) * gx2 + (PV[1] * m_w - PV[3] * mul2) * gy2;
+      gmy += (PV[4] * m_w - PV[7] * mul1) * gx2 + (PV[5] * m_w - PV[7] * mul2) * gy2;
+      gmz += (PV[8] * m_w - PV[11] * mul1) * gx2 + (PV[9] * m_w - PV[11] * mul2) * gy2;
+    }
+    if (use_sh) {
+      if (!sh_loaded) {
+        const float* sp = sh + sg * (size_t)K * 3;
+        if (d.sh_layout == PS_SH_GK3) {
+#pragma unroll
+          for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) shc[k * 3 + ch] = sp[k * 3 + ch];
+        } else {
+#pragma unroll
+          for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) shc[k * 3 + ch] = sp[ch * K + k];
+        }
+        sh_loaded = true;
+      }
+      const float* cam = vp + PS_VIEW_CAMPOS;
+      const float ox = mx - cam[0], oy = my - cam[1], oz = mz - cam[2];
+      const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+      const float x = ox * inv, y = oy * inv, z = oz * inv;
+      float bas[25], bx[25], by[25], bz[25];
+      sh_basis(DEG, x, y, z, bas);
+      sh_basis_grad(DEG, x, y, z, bx, by, bz);
+      const float gch[3] = {(clamp_bits & 1u) ? 0.f : gr0, (clamp_bits & 2u) ? 0.f : gr1,
+                            (clamp_bits & 4u) ? 0.f : gr2};
+      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float sv = shc[k * 3 + ch] * gch[ch];
+          dsh[k * 3 + ch] += bas[k] * gch[ch];
+          ddx += bx[k] * sv; ddy += by[k] * sv; ddz += bz[k] * sv;
+        }
+      }
+      const float dot = x * ddx + y * ddy + z * ddz;
+      gmx += (ddx - x * dot) * inv;
+      gmy += (ddy - y * dot) * inv;
+      gmz += (ddz - z * dot) * inv;
+    }
+    gm[0] += scale * gmx; gm[1] += scale * gmy; gm[2] += scale * gmz;
+    gop += g_op;
+  }
+
+  float* om = dL_dmeans + sg * 3;
+  om[0] = gm[0]; om[1] = gm[1]; om[2] = gm[2];
+  if (d.cov_layout == PS_COV_6) {
+    float* oc = dL_dcov + sg * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) oc[k] = gc[k];
+  } else {
+    float* oc = dL_dcov + sg * 9;
+    oc[0] = gc[0]; oc[1] = gc[1]; oc[2] = gc[2]; oc[3] = 0.f; oc[4] = gc[3]; oc[5] = gc[4];
+    oc[6] = 0.f; oc[7] = 0.f; oc[8] = gc[5];
+  }
+  dL_dopacity[sg] = gop;
+  if (use_sh && dL_dsh) {
+    float* os = dL_dsh + sg * (size_t)K * 3;
+    const bool gk3 = d.sh_layout == PS_SH_GK3;
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) os[gk3 ? k * 3 + ch : ch * K + k] = dsh[k * 3 + ch];
+    for (int k = NB; k < K; ++k)
+      for (int ch = 0; ch < 3; ++ch) os[gk3 ? k * 3 + ch : ch * K + k] = 0.f;
+  }
+}
+
+void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
+                                const float* sh, const float* view_params, const float* records,
+                                const int32_t* radii, const float* grad2d, float* dL_dmeans,
+                                float* dL_dcov, float* dL_dsh, float* dL_dcolors,
+                                float* dL_dopacity, float* dL_dmeans2D, hipStream_t st) {
+  dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
+#define PS_LAUNCH(DEG)                                                                         \
+  hipLaunchKernelGGL(preprocess_backward_kernel<DEG>, grid, block, 0, st, d, means, cov, sh,   \
+                     view_params, records, radii, grad2d, dL_dmeans, dL_dcov, dL_dsh,          \
+                     dL_dcolors, dL_dopacity, dL_dmeans2D)
+  const int deg = sh ? d.sh_degree : 0;
+  switch (deg) {
+    case 0: PS_LAUNCH(0); break;
+    case 1: PS_LAUNCH(1); break;
+    case 2: PS_LAUNCH(2); break;
+    case 3: PS_LAUNCH(3); break;
+    default: PS_LAUNCH(4); break;
+  }
+#undef PS_LAUNCH
+}
+
+}  // namespace ps

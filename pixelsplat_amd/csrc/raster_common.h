@@ -1,0 +1,128 @@
+// Shared declarations of the gfx950 rasterizer kernels (internal; the public surface is
+// include/pixelsplat_hip.h).  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pixelsplat_hip.h"
+
+namespace ps {
+
+constexpr int kWave = 64;
+constexpr int kTile = 16;               // 16x16 pixel tiles (bin parity with the reference)
+constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
+constexpr int kRecFloats = 12;          // one 48-byte record per (view, gaussian)
+constexpr int kGradFloats = 9;          // dxy(2) dconic(3) dopacity(1) drgb(3)
+
+// sort geometry
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 16;
+constexpr int kSortChunk = kSortThreads * kSortItems;  // 4096 keys per block
+
+struct Dims {
+  int S, vps, V, G, H, W, gx, gy, tiles;
+  size_t N;   // V * G
+  size_t P;   // H * W
+  int nblk;   // sort blocks per view
+};
+
+__host__ __device__ inline Dims make_dims(const PsRasterDesc& d) {
+  Dims m;
+  m.S = d.n_scenes; m.vps = d.views_per_scene; m.V = m.S * m.vps; m.G = d.n_gaussians;
+  m.H = d.height; m.W = d.width;
+  m.gx = (m.W + kTile - 1) / kTile; m.gy = (m.H + kTile - 1) / kTile; m.tiles = m.gx * m.gy;
+  m.N = (size_t)m.V * m.G; m.P = (size_t)m.H * m.W;
+  m.nblk = (m.G + kSortChunk - 1) / kSortChunk;
+  return m;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct TempLayout {
+  size_t keys_a, keys_b, vals_a, vals_b, block_hist, grad2d, total;
+};
+
+inline TempLayout make_temp_layout(const PsRasterDesc& d) {
+  Dims m = make_dims(d);
+  TempLayout t; size_t o = 0;
+  t.keys_a = o; o = align_up(o + m.N * 4);
+  t.keys_b = o; o = align_up(o + m.N * 4);
+  t.vals_a = o; o = align_up(o + m.N * 4);
+  t.vals_b = o; o = align_up(o + m.N * 4);
+  t.block_hist = o; o = align_up(o + (size_t)m.V * 256 * m.nblk * 4);
+  t.grad2d = 0;  // backward reuses the buffer from offset 0
+  t.total = o;
+  size_t bwd = align_up(m.N * kGradFloats * 4);
+  if (bwd > t.total) t.total = bwd;
+  return t;
+}
+
+inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
+  Dims m = make_dims(d);
+  PsRasterStateLayout s; size_t o = 0;
+  s.records = o; o = align_up(o + m.N * kRecFloats * 4);
+  s.rects = o; o = align_up(o + m.N * 8);
+  s.sorted_idx = o; o = align_up(o + m.N * 4);
+  s.sorted_rect = o; o = align_up(o + m.N * 8);
+  s.n_vis = o; o = align_up(o + (size_t)m.V * 4);
+  s.final_T = o; o = align_up(o + (size_t)m.V * m.P * 4);
+  s.n_contrib = o; o = align_up(o + (size_t)m.V * m.P * 4);
+  s.tile_end = o; o = align_up(o + (size_t)m.V * m.tiles * 8);
+  s.total = o;
+  return s;
+}
+
+// ---- launchers (one per translation unit) -------------------------------------------
+void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
+                               const float* sh, const float* colors, const float* opacity,
+                               const float* view_params, float* records, uint32_t* keys,
+                               uint2* rects, int32_t* radii,
+                               uint32_t* n_vis, hipStream_t st);
+
+void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                 uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
+                 const uint2* rects, uint2* sorted_rect, const uint32_t* n_vis, hipStream_t st);
+
+void launch_tiles_forward(const PsRasterDesc& d, const float* records, const uint32_t* sorted_idx,
+                          const uint2* sorted_rect, const uint32_t* n_vis,
+                          const float* view_params, float* out_color, float* final_T,
+                          uint32_t* n_contrib, uint32_t* tile_end, hipStream_t st);
+
+void launch_export_bins(const PsRasterDesc& d, const uint32_t* sorted_idx,
+                        const uint2* sorted_rect, const uint32_t* n_vis, uint32_t* tile_counts,
+                        const uint32_t* tile_offsets, uint32_t* point_list, size_t capacity,
+                        hipStream_t st);
+
+void launch_tiles_backward(const PsRasterDesc& d, const float* records,
+                           const uint32_t* sorted_idx, const uint2* sorted_rect,
+                           const float* view_params, const float* final_T,
+                           const uint32_t* n_contrib, const uint32_t* tile_end,
+                           const float* dL_dcolor, float* grad2d, hipStream_t st);
+
+void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
+                                const float* sh, const float* view_params, const float* records,
+                                const int32_t* radii, const float* grad2d, float* dL_dmeans,
+                                float* dL_dcov, float* dL_dsh, float* dL_dcolors,
+                                float* dL_dopacity, float* dL_dmeans2D, hipStream_t st);
+
+// ---- device helpers -------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+
+// LDS hand-off between lanes of ONE wave (no s_barrier: the four waves of a block are
+// independent here).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// rect packed as uint2: .x = xmin | ymin << 16, .y = xmax | ymax << 16 (in tiles)
+__device__ __forceinline__ bool rect_covers(uint2 r, uint32_t tx, uint32_t ty) {
+  const uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu, ymax = r.y >> 16;
+  return (xmin <= tx) & (tx < xmax) & (ymin <= ty) & (ty < ymax);
+}
+
+}  // namespace ps

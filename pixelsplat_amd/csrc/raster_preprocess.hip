@@ -1,0 +1,203 @@
+// Per-Gaussian preprocess (forward): frustum cull, projection, EWA 2-D covariance, conic,
+// 3-sigma radius, tile rect, SH colour; one thread per scene Gaussian looping over the
+// scene's views so {mean, cov, SH, opacity} are read from HBM once per scene, not once per
+// view (the reference materialises v copies: decoder_splatting_cuda.py:53-56).
+//
+// Semantics: SURVEY.md Appendix A.1 -- what `GaussianRasterizer.forward` computes per
+// Gaussian for the call at /root/reference/src/model/decoder/cuda_splatting.py:117-124.
+//
+// THIS TRANSLATION UNIT IS BUILT WITH -ffp-contract=off: radius, tile rect and the depth
+// sort key are integer-valued functions of this arithmetic and must be bit-exact.
+#include "raster_common.h"
+#include "sh_math.h"
+
+namespace ps {
+
+__device__ __forceinline__ int sat_int(float v) {  // trunc, saturating, NaN -> -2^30
+  if (!(v > -1073741824.0f)) return -1073741824;
+  if (v > 1073741824.0f) return 1073741824;
+  return (int)v;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) {
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
+                          const float* __restrict__ cov, const float* __restrict__ sh,
+                          const float* __restrict__ colors, const float* __restrict__ opacity,
+                          const float* __restrict__ view_params, float* __restrict__ records,
+                          uint32_t* __restrict__ keys, uint2* __restrict__ rects,
+                          int32_t* __restrict__ radii, uint32_t* __restrict__ n_vis) {
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  const int G = d.n_gaussians, vps = d.views_per_scene, H = d.height, W = d.width;
+  const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  const bool active = g < G;
+  const size_t sg = (size_t)s * G + (active ? g : 0);
+
+  float m0[3], c6[6], opac;
+  {
+    const float* mp = means + sg * 3;
+    m0[0] = mp[0]; m0[1] = mp[1]; m0[2] = mp[2];
+    if (d.cov_layout == PS_COV_6) {
+      const float* cp = cov + sg * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = cp[k];
+    } else {
+      const float* cp = cov + sg * 9;
+      c6[0] = cp[0]; c6[1] = cp[1]; c6[2] = cp[2]; c6[3] = cp[4]; c6[4] = cp[5]; c6[5] = cp[8];
+    }
+    opac = opacity[sg];
+  }
+  float shc[NB * 3];
+  bool sh_loaded = false;
+
+  for (int j = 0; j < vps; ++j) {
+    const int v = s * vps + j;
+    const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
+    const float* V = vp + PS_VIEW_VIEWMATRIX;
+    const float* PV = vp + PS_VIEW_PROJMATRIX;
+    const float tanfovx = vp[PS_VIEW_TANFOVX], tanfovy = vp[PS_VIEW_TANFOVY];
+    const float scale = vp[PS_VIEW_SCALE];
+    const float scale2 = scale * scale;
+    const size_t vg = (size_t)v * G + (active ? g : 0);
+
+    const float mx = m0[0] * scale, my = m0[1] * scale, mz = m0[2] * scale;
+    const float tvx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+    const float tvy = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+    const float tvz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+    bool vis = active && (tvz > d.near_cull);
+
+    int radius = 0, xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+    float px = 0.f, py = 0.f, con_x = 0.f, con_y = 0.f, con_z = 0.f;
+    if (vis) {
+      const float hx = PV[0] * mx + PV[4] * my + PV[8] * mz + PV[12];
+      const float hy = PV[1] * mx + PV[5] * my + PV[9] * mz + PV[13];
+      const float hw = PV[3] * mx + PV[7] * my + PV[11] * mz + PV[15];
+      const float pw = 1.0f / (hw + d.w_eps);
+      const float ppx = hx * pw, ppy = hy * pw;
+
+      const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+      const float limx = d.guard * tanfovx, limy = d.guard * tanfovy;
+      const float txtz = tvx / tvz, tytz = tvy / tvz;
+      const float tx = fminf(limx, fmaxf(-limx, txtz)) * tvz;
+      const float ty = fminf(limy, fmaxf(-limy, tytz)) * tvz;
+      const float J00 = fx / tvz, J02 = -(fx * tx) / (tvz * tvz);
+      const float J11 = fy / tvz, J12 = -(fy * ty) / (tvz * tvz);
+      const float M00 = J00 * V[0] + J02 * V[2], M01 = J00 * V[4] + J02 * V[6],
+                  M02 = J00 * V[8] + J02 * V[10];
+      const float M10 = J11 * V[1] + J12 * V[2], M11 = J11 * V[5] + J12 * V[6],
+                  M12 = J11 * V[9] + J12 * V[10];
+      const float S00 = c6[0] * scale2, S01 = c6[1] * scale2, S02 = c6[2] * scale2,
+                  S11 = c6[3] * scale2, S12 = c6[4] * scale2, S22 = c6[5] * scale2;
+      const float a0 = S00 * M00 + S01 * M01 + S02 * M02;
+      const float a1 = S01 * M00 + S11 * M01 + S12 * M02;
+      const float a2 = S02 * M00 + S12 * M01 + S22 * M02;
+      const float b0 = S00 * M10 + S01 * M11 + S02 * M12;
+      const float b1 = S01 * M10 + S11 * M11 + S12 * M12;
+      const float b2 = S02 * M10 + S12 * M11 + S22 * M12;
+      const float c00 = (M00 * a0 + M01 * a1 + M02 * a2) + d.lowpass;
+      const float c01 = M10 * a0 + M11 * a1 + M12 * a2;
+      const float c11 = (M10 * b0 + M11 * b1 + M12 * b2) + d.lowpass;
+      const float det = c00 * c11 - c01 * c01;
+      if (det == 0.0f || det != det) {
+        vis = false;
+      } else {
+        const float det_inv = 1.0f / det;
+        con_x = c11 * det_inv; con_y = -c01 * det_inv; con_z = c00 * det_inv;
+        const float mid = 0.5f * (c00 + c11);
+        const float sq = sqrtf(fmaxf(d.lambda_floor, mid * mid - det));
+        const float l1 = mid + sq, l2 = mid - sq;
+        radius = sat_int(ceilf(3.0f * sqrtf(fmaxf(l1, l2))));
+        px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+        py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+        const float rf = (float)radius;
+        xmin = clampi(sat_int((px - rf) / 16.0f), 0, gx);
+        ymin = clampi(sat_int((py - rf) / 16.0f), 0, gy);
+        xmax = clampi(sat_int((px + rf + 15.0f) / 16.0f), 0, gx);
+        ymax = clampi(sat_int((py + rf + 15.0f) / 16.0f), 0, gy);
+        if ((xmax - xmin) * (ymax - ymin) <= 0) vis = false;
+      }
+    }
+
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t clamp_bits = 0;
+    if (vis) {
+      if (sh != nullptr) {
+        if (!sh_loaded) {
+          const int K = d.sh_coeffs;
+          const float* sp = sh + sg * (size_t)K * 3;
+          if (d.sh_layout == PS_SH_GK3) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) shc[k * 3 + c] = sp[k * 3 + c];
+          } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) shc[k * 3 + c] = sp[c * K + k];
+          }
+          sh_loaded = true;
+        }
+        const float* cam = vp + PS_VIEW_CAMPOS;
+        float dx = mx - cam[0], dy = my - cam[1], dz = mz - cam[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        float b[25];
+        sh_basis(DEG, dx, dy, dz, b);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < NB; ++k) acc = acc + b[k] * shc[k * 3 + c];
+          acc = acc + 0.5f;
+          if (acc < 0.f) clamp_bits |= (1u << c);
+          rgb[c] = fmaxf(acc, 0.f);
+        }
+      } else {
+        const float* cp = colors + vg * 3;
+        rgb[0] = cp[0]; rgb[1] = cp[1]; rgb[2] = cp[2];
+      }
+    }
+
+    if (active) {
+      radii[vg] = vis ? radius : 0;
+      keys[vg] = vis ? __float_as_uint(tvz) : kCulledKey;
+      if (vis) {
+        rects[vg] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16),
+                               (uint32_t)xmax | ((uint32_t)ymax << 16));
+        float4* r = reinterpret_cast<float4*>(records + vg * kRecFloats);
+        r[0] = make_float4(px, py, con_x, con_y);
+        r[1] = make_float4(con_z, opac, rgb[0], rgb[1]);
+        r[2] = make_float4(rgb[2], tvz, __int_as_float(radius), __uint_as_float(clamp_bits));
+      }
+    }
+    const uint64_t m = __ballot(vis);
+    if (m != 0ull && lane_id() == 0) atomicAdd(&n_vis[v], (uint32_t)__popcll(m));
+  }
+}
+
+void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
+                               const float* sh, const float* colors, const float* opacity,
+                               const float* view_params, float* records, uint32_t* keys,
+                               uint2* rects, int32_t* radii, uint32_t* n_vis, hipStream_t st) {
+  dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
+#define PS_LAUNCH(DEG)                                                                       \
+  hipLaunchKernelGGL(preprocess_forward_kernel<DEG>, grid, block, 0, st, d, means, cov, sh,  \
+                     colors, opacity, view_params, records, keys, rects, radii, n_vis)
+  const int deg = sh ? d.sh_degree : 0;
+  switch (deg) {
+    case 0: PS_LAUNCH(0); break;
+    case 1: PS_LAUNCH(1); break;
+    case 2: PS_LAUNCH(2); break;
+    case 3: PS_LAUNCH(3); break;
+    default: PS_LAUNCH(4); break;
+  }
+#undef PS_LAUNCH
+}
+
+}  // namespace ps

@@ -1,0 +1,153 @@
+// Per-view stable LSD radix sort of (depth bits -> Gaussian id), 4 passes x 8 bits, all
+// views in one launch per pass.  Culled Gaussians carry key 0xFFFFFFFF and land behind the
+// n_vis[v] visible ones.  Stability + ids emitted in ascending order give exactly the order
+// of the reference's (tile | depth) stable sort restricted to any tile, so
+// the per-tile lists the tile kernels walk are bit-identical to the reference's bins.
+//
+// Pass = histogram (per 4096-key block) -> per-view scan -> stable scatter.  Ranking inside a
+// block is wave-synchronous: 8 ballots build the mask of lanes that share my digit
+// (wave64 "match"), rank = popcount below me, a per-wave LDS counter carries the running
+// digit offsets across the wave's 16 sequential 64-key rows.
+#include "raster_common.h"
+
+namespace ps {
+
+__global__ void __launch_bounds__(kSortThreads)
+sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist, int G,
+                 int nblk, int shift) {
+  __shared__ uint32_t h[256];
+  const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  h[t] = 0;
+  __syncthreads();
+  const uint32_t* k = keys + (size_t)v * G;
+  const int base = blk * kSortChunk;
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int p = base + i * kSortThreads + t;
+    if (p < G) atomicAdd(&h[(k[p] >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  block_hist[((size_t)v * 256 + t) * nblk + blk] = h[t];
+}
+
+// one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order
+__global__ void __launch_bounds__(256)
+sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk) {
+  __shared__ uint32_t tot[256];
+  const int v = blockIdx.x, dgt = threadIdx.x;
+  uint32_t* row = block_hist + ((size_t)v * 256 + dgt) * nblk;
+  uint32_t sum = 0;
+  for (int b = 0; b < nblk; ++b) { const uint32_t c = row[b]; row[b] = sum; sum += c; }
+  tot[dgt] = sum;
+  __syncthreads();
+  // exclusive scan over 256 digit totals (Hillis-Steele in LDS)
+  uint32_t x = sum;
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t y = (dgt >= off) ? tot[dgt - off] : 0u;
+    __syncthreads();
+    x += y; tot[dgt] = x;
+    __syncthreads();
+  }
+  const uint32_t excl = x - sum;
+  for (int b = 0; b < nblk; ++b) row[b] += excl;
+}
+
+template <bool IOTA_VALS>
+__global__ void __launch_bounds__(kSortThreads)
+sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                    const uint32_t* __restrict__ block_hist, int G, int nblk, int shift) {
+  __shared__ uint32_t cnt[4][256];   // per-wave running digit counts
+  __shared__ uint32_t base[4][256];  // global start of (wave, digit)
+  const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const int w = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cnt[i][t] = 0;
+  __syncthreads();
+
+  const size_t vo = (size_t)v * G;
+  const int start = blk * kSortChunk + w * (kSortChunk / 4);
+  uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
+  const uint64_t lt = lanemask_lt();
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int p = start + i * kWave + lane;
+    const bool valid = p < G;
+    key[i] = valid ? keys_in[vo + p] : 0u;
+    val[i] = valid ? (IOTA_VALS ? (uint32_t)p : vals_in[vo + p]) : 0u;
+    const uint32_t dg = (key[i] >> shift) & 0xFFu;
+    uint64_t mask = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (dg >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      mask &= bit ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t prefix = cnt[w][dg];
+      const uint32_t r = (uint32_t)__popcll(mask & lt);
+      rank[i] = prefix + r;
+      if (r == 0) cnt[w][dg] = prefix + (uint32_t)__popcll(mask);
+    } else {
+      rank[i] = 0;
+    }
+    wave_lds_sync();
+  }
+  __syncthreads();
+  {
+    uint32_t b = block_hist[((size_t)v * 256 + t) * nblk + blk];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { base[i][t] = b; b += cnt[i][t]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int p = start + i * kWave + lane;
+    if (p < G) {
+      const uint32_t dg = (key[i] >> shift) & 0xFFu;
+      const uint32_t pos = base[w][dg] + rank[i];
+      keys_out[vo + pos] = key[i];
+      vals_out[vo + pos] = val[i];
+    }
+  }
+}
+
+// sorted_rect[v][pos] = rects[v][sorted_idx[v][pos]] for the visible prefix
+__global__ void __launch_bounds__(256)
+gather_rects_kernel(const uint32_t* __restrict__ sorted_idx, const uint2* __restrict__ rects,
+                    uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, int G) {
+  const int v = blockIdx.y;
+  const uint32_t n = n_vis[v];
+  const size_t vo = (size_t)v * G;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
+    sorted_rect[vo + p] = rects[vo + sorted_idx[vo + p]];
+}
+
+void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                 uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
+                 const uint2* rects, uint2* sorted_rect, const uint32_t* n_vis, hipStream_t st) {
+  const Dims m = make_dims(d);
+  dim3 grid(m.nblk, m.V), block(kSortThreads);
+  uint32_t* kin = keys_a; uint32_t* kout = keys_b;
+  uint32_t* vin = nullptr; uint32_t* vout = vals_b;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    hipLaunchKernelGGL(sort_hist_kernel, grid, block, 0, st, kin, block_hist, m.G, m.nblk, shift);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(256), 0, st, block_hist, m.nblk);
+    if (pass == 0)
+      hipLaunchKernelGGL(sort_scatter_kernel<true>, grid, block, 0, st, kin, vin, kout, vout,
+                         block_hist, m.G, m.nblk, shift);
+    else
+      hipLaunchKernelGGL(sort_scatter_kernel<false>, grid, block, 0, st, kin, vin, kout, vout,
+                         block_hist, m.G, m.nblk, shift);
+    // ping-pong: keys a<->b ; vals: (iota)->b->a->b->sorted_idx
+    uint32_t* tk = kin; kin = kout; kout = tk;
+    vin = vout;
+    vout = (pass == 0) ? vals_a : (pass == 1) ? vals_b : sorted_idx;
+  }
+  dim3 ggrid((m.G + 255) / 256 < 1024 ? (m.G + 255) / 256 : 1024, m.V);
+  hipLaunchKernelGGL(gather_rects_kernel, ggrid, dim3(256), 0, st, sorted_idx, rects,
+                     sorted_rect, n_vis, m.G);
+}
+
+}  // namespace ps

@@ -14,7 +14,26 @@ from pixelsplat_amd.synthetic import make_workload  # noqa: F401  (re-export)
 
 
 def oracle_view_inputs(g, cams, b: int, v: int, use_sh: bool = True, bg=None,
-                       scale_invariant: bool = True, dtype=np.float32) -> dict:
+                       scale_invariant: bool = True, dtype=np.float32, view_params=None) -> dict:
+    """`view_params` (one [48] row of the product's packed per-view block) overrides the
+    matrices so the oracle sees bit-identical camera inputs (CPU and GPU `linalg.inv` may
+    differ in the last bit)."""
+    if view_params is not None:
+        vp = np.asarray(view_params, np.float32)
+        scale = torch.tensor(vp[40])
+        means = g.means[b] * scale
+        cov = g.covariances[b] * scale ** 2
+        row, col = torch.triu_indices(3, 3)
+        out = dict(
+            means=means.numpy().astype(dtype), cov6=cov[:, row, col].numpy().astype(dtype),
+            opacity=g.opacities[b].numpy().astype(dtype), view=vp[0:16].astype(dtype),
+            proj=vp[16:32].astype(dtype), campos=vp[32:35].astype(dtype),
+            bg=vp[37:40].astype(dtype), tanfovx=float(vp[35]), tanfovy=float(vp[36]))
+        if use_sh:
+            d_sh = g.harmonics.shape[-1]
+            out["sh"] = g.harmonics[b].permute(0, 2, 1).contiguous().numpy().astype(dtype)
+            out["sh_degree"] = int(round(d_sh ** 0.5)) - 1
+        return out
     scale = 1 / cams.near[b, v] if scale_invariant else torch.tensor(1.0)
     ext = cams.extrinsics[b, v].clone()
     ext[:3, 3] = ext[:3, 3] * scale

@@ -1,0 +1,92 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/pixelsplat_hip.h declares; argument validation and the
+no-fallback rule of the product path.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pixelsplat_amd import build as hip_build
+    hip_build.build()
+    from pixelsplat_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "pixelsplat_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(ps_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 13
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    from pixelsplat_amd import _lib
+    assert set(_lib.EXPORTS) == names
+
+
+def test_desc_defaults_and_sizes(lib):
+    from pixelsplat_amd import _lib
+    d = _lib.default_desc()
+    assert abs(d.near_cull - 0.2) < 1e-7 and abs(d.alpha_min - 1 / 255) < 1e-9
+    assert lib.ps_raster_state_bytes(C.byref(d)) == 0  # G = 0: invalid descriptor
+    d.n_scenes, d.views_per_scene, d.n_gaussians, d.height, d.width = 7, 4, 393216, 256, 256
+    d.sh_degree, d.sh_coeffs = 4, 25
+    state, temp = lib.ps_raster_state_bytes(C.byref(d)), lib.ps_raster_temp_bytes(C.byref(d))
+    n = 28 * 393216
+    assert state >= n * (48 + 8 + 4 + 8) and state < n * 80 + (1 << 24)
+    assert temp >= n * 36
+    lay = _lib.PsRasterStateLayout()
+    assert lib.ps_raster_state_layout(C.byref(d), C.byref(lay)) == 0
+    offs = [lay.records, lay.rects, lay.sorted_idx, lay.sorted_rect, lay.n_vis, lay.final_T,
+            lay.n_contrib, lay.tile_end, lay.total]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+
+
+def test_bad_arguments_are_status_codes_not_crashes(lib):
+    from pixelsplat_amd import _lib
+    d = _lib.default_desc()
+    d.n_gaussians, d.height, d.width = 16, 32, 32
+    rc = lib.ps_raster_forward(C.byref(d), None, None, None, None, None, None, None, None, None,
+                               0, None, 0, None)
+    assert rc == -1
+    assert b"bad argument" in lib.ps_status_string(rc)
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "ps_raster_forward")
+    assert lib.ps_raster_export_bins(C.byref(d), None, 0, None, None, None, 0, None) == -1
+    assert lib.ps_profile_group_count() >= 5
+
+
+def test_product_path_refuses_cpu_tensors(lib):
+    """No CPU fallback: the drop-in module raises instead of computing on the host."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    g = 8
+    s = GaussianRasterizationSettings(
+        image_height=32, image_width=32, tanfovx=0.5, tanfovy=0.5, bg=torch.zeros(3),
+        scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0,
+        campos=torch.zeros(3), prefiltered=False, debug=False)
+    r = GaussianRasterizer(s)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(means3D=torch.zeros(g, 3), means2D=torch.zeros(g, 3), opacities=torch.ones(g, 1),
+          colors_precomp=torch.ones(g, 3), cov3D_precomp=torch.ones(g, 6))
+    with pytest.raises(Exception, match="excatly one"):
+        r(means3D=torch.zeros(g, 3), means2D=torch.zeros(g, 3), opacities=torch.ones(g, 1),
+          cov3D_precomp=torch.ones(g, 6))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from pixelsplat_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.load()
+
+
+def test_graft_entry_build():
+    import __graft_entry__ as ge
+    ge.build()
