@@ -134,7 +134,7 @@ def main():
     # D = sum of tile-list lengths (reported; enters the algorithmic-bytes figure)
     img, aux = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v,
                            return_aux=True)
-    counts, _, _ = export_bins(aux["cfg"], aux["state"])
+    counts, _, _ = export_bins(aux["cfg"], aux["state"], aux["layout"], aux["point_list"])
     D_total = int(counts.to(torch.int64).sum().item())
     n_visible = int((aux["radii"] > 0).sum().item())
     vps_np = aux["view_params"].cpu().numpy()

@@ -33,7 +33,8 @@ typedef enum PsStatus {
   PS_ERR_BAD_ARG = -1,     /* null pointer / inconsistent descriptor            */
   PS_ERR_WORKSPACE = -2,   /* state/temp buffer smaller than ps_raster_*_bytes  */
   PS_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after a launch    */
-  PS_ERR_UNSUPPORTED = -4  /* e.g. sh_degree > 4, image wider than 65535 tiles  */
+  PS_ERR_UNSUPPORTED = -4, /* e.g. sh_degree > 4, image wider than 32767 tiles  */
+  PS_ERR_CAPACITY = -5     /* D (sum of tile-list lengths) exceeds the point-list capacity */
 } PsStatus;
 
 /* layout selectors */
@@ -90,7 +91,9 @@ typedef struct PsRasterStateLayout {
   size_t n_vis;       /* uint32[V]                                                     */
   size_t final_T;     /* float[V][P]                                                   */
   size_t n_contrib;   /* uint32[V][P]: 1-based index (within the tile's list) of the last contributor */
-  size_t tile_end;    /* uint32[V][T][2]: (max n_contrib in tile, sorted position + 1 of that entry) */
+  size_t tile_end;    /* uint32[V][T]: max n_contrib in the tile (where the backward walk starts) */
+  size_t tile_ranges; /* uint32[V][T][2]: (start, count) of the tile's list in point_list     */
+  size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
   size_t total;
 } PsRasterStateLayout;
 
@@ -107,12 +110,33 @@ int ps_raster_state_layout(const PsRasterDesc* desc, PsRasterStateLayout* out);
  *   opacity    float[S][G]
  *   view_params float[V][PS_VIEW_STRIDE]
  *   out_color  float[V][3][H][W]      out_radii int32[V][G]
+ *   point_list uint32[list_capacity]: receives the per-(view,tile) lists of Gaussian ids in
+ *              blend order (tile t of view v at state.tile_ranges[v][t] = (start,count)) --
+ *              the bit-exact counterpart of the reference's sorted point list + ranges.
+ *
+ * The list length D is data dependent (the reference reads it back per view and resizes,
+ * SURVEY.md 2.1 "num_rendered").  Two ways to size point_list:
+ *   - ps_raster_forward_plan  (preprocess, depth sort, tile counts; D -> state.num_rendered)
+ *     ps_raster_check         (ONE host read-back of D per batch of views)
+ *     ps_raster_forward_render(bins + blend) with list_capacity >= D; or
+ *   - ps_raster_forward with a capacity guess and no host sync at all: if D > capacity the
+ *     overflow flag in state.num_rendered is raised, the image is invalid, and
+ *     ps_raster_check / ps_raster_backward return PS_ERR_CAPACITY.
+ * `temp` must be the same buffer for _plan and _render (it carries the tile counts).
  */
 int ps_raster_forward(const PsRasterDesc* desc, const float* means, const float* cov,
                       const float* sh, const float* colors, const float* opacity,
                       const float* view_params, float* out_color, int32_t* out_radii,
                       void* state, size_t state_bytes, void* temp, size_t temp_bytes,
-                      void* stream);
+                      uint32_t* point_list, size_t list_capacity, void* stream);
+int ps_raster_forward_plan(const PsRasterDesc* desc, const float* means, const float* cov,
+                           const float* sh, const float* colors, const float* opacity,
+                           const float* view_params, int32_t* out_radii, void* state,
+                           size_t state_bytes, void* temp, size_t temp_bytes, void* stream);
+int ps_raster_forward_render(const PsRasterDesc* desc, const float* view_params,
+                             float* out_color, void* state, size_t state_bytes, void* temp,
+                             size_t temp_bytes, uint32_t* point_list, size_t list_capacity,
+                             void* stream);
 
 /* Backward.  Replaces _RasterizeGaussians.backward of the external module.
  *   radii       int32[V][G]  (the forward's out_radii)
@@ -128,21 +152,15 @@ int ps_raster_backward(const PsRasterDesc* desc, const float* means, const float
                        const float* sh, const float* colors, const float* opacity,
                        const float* view_params, const int32_t* radii, const float* dL_dcolor,
                        const void* state, size_t state_bytes, void* temp, size_t temp_bytes,
-                       float* dL_dmeans,
+                       const uint32_t* point_list, size_t list_capacity, float* dL_dmeans,
                        float* dL_dcov, float* dL_dsh, float* dL_dcolors, float* dL_dopacity,
                        float* dL_dmeans2D, void* stream);
 
-/* Debug/parity export of the per-tile bins the forward pass walked implicitly:
- *   tile_counts uint32[V][T]   (number of Gaussians whose rect covers the tile)
- *   point_list  uint32[capacity] concatenated per-(view,tile) lists of Gaussian ids in
- *               blend order, tile t of view v starting at the exclusive prefix sum of
- *               tile_counts; written only if point_list != NULL (call once with NULL to
- *               size it).  Bit-exact counterpart of the reference's sorted point list +
- *               tile ranges.
- */
-int ps_raster_export_bins(const PsRasterDesc* desc, const void* state, size_t state_bytes,
-                          uint32_t* tile_counts, const uint32_t* tile_offsets,
-                          uint32_t* point_list, size_t capacity, void* stream);
+/* Reads back (synchronising the stream) D = sum of tile-list lengths of the last
+ * forward / forward_plan on this state, and whether it overflowed the capacity given to
+ * ps_raster_forward.  Returns PS_OK, or PS_ERR_CAPACITY. */
+int ps_raster_check(const PsRasterDesc* desc, const void* state, size_t state_bytes,
+                    uint64_t* num_rendered, void* stream);
 
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents

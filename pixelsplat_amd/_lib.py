@@ -33,14 +33,15 @@ class PsRasterDesc(C.Structure):
 class PsRasterStateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "records", "rects", "sorted_idx", "sorted_rect", "n_vis", "final_T", "n_contrib",
-        "tile_end", "total")]
+        "tile_end", "tile_ranges", "num_rendered", "total")]
 
 
 # every symbol include/pixelsplat_hip.h declares
 EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
-    "ps_raster_state_layout", "ps_raster_forward", "ps_raster_backward",
-    "ps_raster_export_bins", "ps_status_string", "ps_build_info",
+    "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
+    "ps_raster_forward_render", "ps_raster_backward",
+    "ps_raster_check", "ps_status_string", "ps_build_info",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
 ]
 
@@ -74,14 +75,20 @@ def load():
     lib.ps_raster_state_layout.argtypes = [C.POINTER(PsRasterDesc), C.POINTER(PsRasterStateLayout)]
     lib.ps_raster_state_layout.restype = C.c_int
     lib.ps_raster_forward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [
-        vp, C.c_size_t, vp, C.c_size_t, vp]
+        vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp]
     lib.ps_raster_forward.restype = C.c_int
+    lib.ps_raster_forward_plan.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 7 + [
+        vp, C.c_size_t, vp, C.c_size_t, vp]
+    lib.ps_raster_forward_plan.restype = C.c_int
+    lib.ps_raster_forward_render.argtypes = [C.POINTER(PsRasterDesc), vp, vp, vp, C.c_size_t, vp,
+                                             C.c_size_t, vp, C.c_size_t, vp]
+    lib.ps_raster_forward_render.restype = C.c_int
     lib.ps_raster_backward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [
-        vp, C.c_size_t, vp, C.c_size_t] + [vp] * 6 + [vp]
+        vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t] + [vp] * 6 + [vp]
     lib.ps_raster_backward.restype = C.c_int
-    lib.ps_raster_export_bins.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t, vp, vp, vp,
-                                          C.c_size_t, vp]
-    lib.ps_raster_export_bins.restype = C.c_int
+    lib.ps_raster_check.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t,
+                                    C.POINTER(C.c_uint64), vp]
+    lib.ps_raster_check.restype = C.c_int
     lib.ps_profile_enable.argtypes = [C.c_int]
     lib.ps_profile_group_count.restype = C.c_int
     lib.ps_profile_group_name.argtypes = [C.c_int]

@@ -11,8 +11,8 @@ using namespace ps;
 namespace {
 
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
-enum Group { G_PRE_FWD = 0, G_SORT, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET, G_COUNT };
-const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tiles_forward",
+enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET, G_COUNT };
+const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
                                     "tiles_backward", "preprocess_backward", "memset"};
 std::atomic<int> g_profile_on{0};
 std::mutex g_profile_mu;
@@ -70,13 +70,42 @@ int ps_raster_state_layout(const PsRasterDesc* d, PsRasterStateLayout* out) {
   return PS_OK;
 }
 
-int ps_raster_forward(const PsRasterDesc* d, const float* means, const float* cov,
-                      const float* sh, const float* colors, const float* opacity,
-                      const float* view_params, float* out_color, int32_t* out_radii,
-                      void* state, size_t state_bytes, void* temp, size_t temp_bytes,
-                      void* stream) {
-  if (!desc_ok(d) || !means || !cov || !opacity || !view_params || !out_color || !out_radii ||
-      !state || !temp)
+namespace {
+struct FwdPtrs {
+  float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
+  float* final_T; uint32_t* n_contrib; uint32_t* tile_end; uint32_t* tile_ranges;
+  uint32_t* num_rendered;
+  uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *bin_counts;
+};
+FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
+  const PsRasterStateLayout L = make_state_layout(d);
+  const TempLayout T = make_temp_layout(d);
+  char* sb = (char*)state; char* tb = (char*)temp;
+  FwdPtrs p;
+  p.records = (float*)(sb + L.records); p.rects = (uint2*)(sb + L.rects);
+  p.sorted_idx = (uint32_t*)(sb + L.sorted_idx); p.sorted_rect = (uint2*)(sb + L.sorted_rect);
+  p.n_vis = (uint32_t*)(sb + L.n_vis); p.final_T = (float*)(sb + L.final_T);
+  p.n_contrib = (uint32_t*)(sb + L.n_contrib); p.tile_end = (uint32_t*)(sb + L.tile_end);
+  p.tile_ranges = (uint32_t*)(sb + L.tile_ranges);
+  p.num_rendered = (uint32_t*)(sb + L.num_rendered);
+  p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
+  p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
+  p.block_hist = (uint32_t*)(tb + T.block_hist); p.bin_counts = (uint32_t*)(tb + T.bin_counts);
+  return p;
+}
+int check_sizes(const PsRasterDesc& d, size_t state_bytes, size_t temp_bytes) {
+  if (state_bytes < make_state_layout(d).total || temp_bytes < make_temp_layout(d).total)
+    return PS_ERR_WORKSPACE;
+  return PS_OK;
+}
+uint32_t clamp_capacity(size_t c) { return c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c; }
+}  // namespace
+
+int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const float* cov,
+                           const float* sh, const float* colors, const float* opacity,
+                           const float* view_params, int32_t* out_radii, void* state,
+                           size_t state_bytes, void* temp, size_t temp_bytes, void* stream) {
+  if (!desc_ok(d) || !means || !cov || !opacity || !view_params || !out_radii || !state || !temp)
     return PS_ERR_BAD_ARG;
   if ((sh == nullptr) == (colors == nullptr)) return PS_ERR_BAD_ARG;  // exactly one
   if (sh) {
@@ -84,54 +113,73 @@ int ps_raster_forward(const PsRasterDesc* d, const float* means, const float* co
     if (d->sh_coeffs < (d->sh_degree + 1) * (d->sh_degree + 1)) return PS_ERR_BAD_ARG;
   }
   const Dims m = make_dims(*d);
-  if (m.gx > 65535 || m.gy > 65535) return PS_ERR_UNSUPPORTED;
-  const PsRasterStateLayout L = make_state_layout(*d);
-  const TempLayout T = make_temp_layout(*d);
-  if (state_bytes < L.total || temp_bytes < T.total) return PS_ERR_WORKSPACE;
+  if (m.gx > 32767 || m.gy > 32767) return PS_ERR_UNSUPPORTED;
+  if (int rc = check_sizes(*d, state_bytes, temp_bytes)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  char* sb = (char*)state; char* tb = (char*)temp;
-  float* records = (float*)(sb + L.records);
-  uint2* rects = (uint2*)(sb + L.rects);
-  uint32_t* sorted_idx = (uint32_t*)(sb + L.sorted_idx);
-  uint2* sorted_rect = (uint2*)(sb + L.sorted_rect);
-  uint32_t* n_vis = (uint32_t*)(sb + L.n_vis);
-  float* final_T = (float*)(sb + L.final_T);
-  uint32_t* n_contrib = (uint32_t*)(sb + L.n_contrib);
-  uint32_t* tile_end = (uint32_t*)(sb + L.tile_end);
-  uint32_t* keys_a = (uint32_t*)(tb + T.keys_a);
-  uint32_t* keys_b = (uint32_t*)(tb + T.keys_b);
-  uint32_t* vals_a = (uint32_t*)(tb + T.vals_a);
-  uint32_t* vals_b = (uint32_t*)(tb + T.vals_b);
-  uint32_t* block_hist = (uint32_t*)(tb + T.block_hist);
-
+  const FwdPtrs p = fwd_ptrs(*d, state, temp);
   {
     Scope sc(G_MEMSET, st);
-    if (hipMemsetAsync(n_vis, 0, (size_t)m.V * 4, st) != hipSuccess) return PS_ERR_LAUNCH;
+    if (hipMemsetAsync(p.n_vis, 0, (size_t)m.V * 4, st) != hipSuccess) return PS_ERR_LAUNCH;
   }
   {
     Scope sc(G_PRE_FWD, st);
-    launch_preprocess_forward(*d, means, cov, sh, colors, opacity, view_params, records, keys_a,
-                              rects, out_radii, n_vis, st);
+    launch_preprocess_forward(*d, means, cov, sh, colors, opacity, view_params, p.records,
+                              p.keys_a, p.rects, out_radii, p.n_vis, st);
   }
   {
     Scope sc(G_SORT, st);
-    launch_sort(*d, keys_a, keys_b, vals_a, vals_b, block_hist, sorted_idx, rects, sorted_rect,
-                n_vis, st);
+    launch_sort(*d, p.keys_a, p.keys_b, p.vals_a, p.vals_b, p.block_hist, p.sorted_idx, p.rects,
+                p.sorted_rect, p.n_vis, st);
+  }
+  {
+    Scope sc(G_BINS, st);
+    launch_bin_count(*d, p.sorted_rect, p.n_vis, p.bin_counts, p.tile_ranges, p.num_rendered, st);
+  }
+  return check_launch();
+}
+
+int ps_raster_forward_render(const PsRasterDesc* d, const float* view_params, float* out_color,
+                             void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                             uint32_t* point_list, size_t list_capacity, void* stream) {
+  if (!desc_ok(d) || !view_params || !out_color || !state || !temp) return PS_ERR_BAD_ARG;
+  if (!point_list && list_capacity > 0) return PS_ERR_BAD_ARG;
+  if (int rc = check_sizes(*d, state_bytes, temp_bytes)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const FwdPtrs p = fwd_ptrs(*d, state, temp);
+  const uint32_t cap = clamp_capacity(list_capacity);
+  {
+    Scope sc(G_BINS, st);
+    launch_bin_write(*d, p.sorted_rect, p.sorted_idx, p.n_vis, p.bin_counts, p.tile_ranges,
+                     p.num_rendered, point_list, cap, st);
   }
   {
     Scope sc(G_TILES_FWD, st);
-    launch_tiles_forward(*d, records, sorted_idx, sorted_rect, n_vis, view_params, out_color,
-                         final_T, n_contrib, tile_end, st);
+    launch_tiles_forward(*d, p.records, p.tile_ranges, point_list, cap, view_params, out_color,
+                         p.final_T, p.n_contrib, p.tile_end, st);
   }
   return check_launch();
+}
+
+int ps_raster_forward(const PsRasterDesc* d, const float* means, const float* cov,
+                      const float* sh, const float* colors, const float* opacity,
+                      const float* view_params, float* out_color, int32_t* out_radii,
+                      void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                      uint32_t* point_list, size_t list_capacity, void* stream) {
+  if (!out_color) return PS_ERR_BAD_ARG;
+  if (int rc = ps_raster_forward_plan(d, means, cov, sh, colors, opacity, view_params, out_radii,
+                                      state, state_bytes, temp, temp_bytes, stream))
+    return rc;
+  return ps_raster_forward_render(d, view_params, out_color, state, state_bytes, temp, temp_bytes,
+                                  point_list, list_capacity, stream);
 }
 
 int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* cov,
                        const float* sh, const float* colors, const float* opacity,
                        const float* view_params, const int32_t* radii, const float* dL_dcolor,
                        const void* state, size_t state_bytes, void* temp, size_t temp_bytes,
-                       float* dL_dmeans, float* dL_dcov, float* dL_dsh, float* dL_dcolors,
-                       float* dL_dopacity, float* dL_dmeans2D, void* stream) {
+                       const uint32_t* point_list, size_t list_capacity, float* dL_dmeans,
+                       float* dL_dcov, float* dL_dsh, float* dL_dcolors, float* dL_dopacity,
+                       float* dL_dmeans2D, void* stream) {
   (void)opacity; (void)colors;
   if (!desc_ok(d) || !means || !cov || !view_params || !radii || !dL_dcolor || !state || !temp ||
       !dL_dmeans || !dL_dcov || !dL_dopacity)
@@ -145,8 +193,9 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   hipStream_t st = (hipStream_t)stream;
   const char* sb = (const char*)state; char* tb = (char*)temp;
   const float* records = (const float*)(sb + L.records);
-  const uint32_t* sorted_idx = (const uint32_t*)(sb + L.sorted_idx);
-  const uint2* sorted_rect = (const uint2*)(sb + L.sorted_rect);
+  const uint32_t* tile_ranges = (const uint32_t*)(sb + L.tile_ranges);
+  const uint32_t capacity = clamp_capacity(list_capacity);
+  if (!point_list && capacity > 0) return PS_ERR_BAD_ARG;
   const float* final_T = (const float*)(sb + L.final_T);
   const uint32_t* n_contrib = (const uint32_t*)(sb + L.n_contrib);
   const uint32_t* tile_end = (const uint32_t*)(sb + L.tile_end);
@@ -157,8 +206,8 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   }
   {
     Scope sc(G_TILES_BWD, st);
-    launch_tiles_backward(*d, records, sorted_idx, sorted_rect, view_params, final_T, n_contrib,
-                          tile_end, dL_dcolor, grad2d, st);
+    launch_tiles_backward(*d, records, tile_ranges, point_list, capacity, view_params, final_T,
+                          n_contrib, tile_end, dL_dcolor, grad2d, st);
   }
   {
     Scope sc(G_PRE_BWD, st);
@@ -169,17 +218,19 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   return check_launch();
 }
 
-int ps_raster_export_bins(const PsRasterDesc* d, const void* state, size_t state_bytes,
-                          uint32_t* tile_counts, const uint32_t* tile_offsets,
-                          uint32_t* point_list, size_t capacity, void* stream) {
+int ps_raster_check(const PsRasterDesc* d, const void* state, size_t state_bytes,
+                    uint64_t* num_rendered, void* stream) {
   if (!desc_ok(d) || !state) return PS_ERR_BAD_ARG;
   const PsRasterStateLayout L = make_state_layout(*d);
   if (state_bytes < L.total) return PS_ERR_WORKSPACE;
-  const char* sb = (const char*)state;
-  launch_export_bins(*d, (const uint32_t*)(sb + L.sorted_idx), (const uint2*)(sb + L.sorted_rect),
-                     (const uint32_t*)(sb + L.n_vis), tile_counts, tile_offsets, point_list,
-                     capacity, (hipStream_t)stream);
-  return check_launch();
+  uint32_t host[2] = {0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(host, (const char*)state + L.num_rendered, 8, hipMemcpyDeviceToHost, st) !=
+          hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return PS_ERR_LAUNCH;
+  if (num_rendered) *num_rendered = host[0];
+  return host[1] ? PS_ERR_CAPACITY : PS_OK;
 }
 
 int ps_profile_enable(int on) { g_profile_on.store(on ? 1 : 0); return PS_OK; }
@@ -209,6 +260,7 @@ const char* ps_status_string(int status) {
     case PS_ERR_WORKSPACE: return "state/temp buffer too small";
     case PS_ERR_LAUNCH: return "HIP launch failed";
     case PS_ERR_UNSUPPORTED: return "unsupported configuration";
+    case PS_ERR_CAPACITY: return "tile point list overflowed (raise PsRasterDesc.list_factor)";
     default: return "unknown status";
   }
 }

@@ -18,12 +18,14 @@ constexpr int kGradFloats = 9;          // dxy(2) dconic(3) dopacity(1) drgb(3)
 constexpr int kSortThreads = 256;
 constexpr int kSortItems = 16;
 constexpr int kSortChunk = kSortThreads * kSortItems;  // 4096 keys per block
+constexpr int kBinChunk = 1024;                        // sorted entries per binning block
 
 struct Dims {
   int S, vps, V, G, H, W, gx, gy, tiles;
   size_t N;   // V * G
   size_t P;   // H * W
   int nblk;   // sort blocks per view
+  int nbin;   // binning blocks per view
 };
 
 __host__ __device__ inline Dims make_dims(const PsRasterDesc& d) {
@@ -33,13 +35,14 @@ __host__ __device__ inline Dims make_dims(const PsRasterDesc& d) {
   m.gx = (m.W + kTile - 1) / kTile; m.gy = (m.H + kTile - 1) / kTile; m.tiles = m.gx * m.gy;
   m.N = (size_t)m.V * m.G; m.P = (size_t)m.H * m.W;
   m.nblk = (m.G + kSortChunk - 1) / kSortChunk;
+  m.nbin = (m.G + kBinChunk - 1) / kBinChunk;
   return m;
 }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct TempLayout {
-  size_t keys_a, keys_b, vals_a, vals_b, block_hist, grad2d, total;
+  size_t keys_a, keys_b, vals_a, vals_b, block_hist, bin_counts, grad2d, total;
 };
 
 inline TempLayout make_temp_layout(const PsRasterDesc& d) {
@@ -50,6 +53,7 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
   t.vals_a = o; o = align_up(o + m.N * 4);
   t.vals_b = o; o = align_up(o + m.N * 4);
   t.block_hist = o; o = align_up(o + (size_t)m.V * 256 * m.nblk * 4);
+  t.bin_counts = o; o = align_up(o + (size_t)m.V * m.nbin * m.tiles * 4);
   t.grad2d = 0;  // backward reuses the buffer from offset 0
   t.total = o;
   size_t bwd = align_up(m.N * kGradFloats * 4);
@@ -67,7 +71,9 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.n_vis = o; o = align_up(o + (size_t)m.V * 4);
   s.final_T = o; o = align_up(o + (size_t)m.V * m.P * 4);
   s.n_contrib = o; o = align_up(o + (size_t)m.V * m.P * 4);
-  s.tile_end = o; o = align_up(o + (size_t)m.V * m.tiles * 8);
+  s.tile_end = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
+  s.tile_ranges = o; o = align_up(o + (size_t)m.V * m.tiles * 8);
+  s.num_rendered = o; o = align_up(o + 8);
   s.total = o;
   return s;
 }
@@ -83,19 +89,23 @@ void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint
                  uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
                  const uint2* rects, uint2* sorted_rect, const uint32_t* n_vis, hipStream_t st);
 
-void launch_tiles_forward(const PsRasterDesc& d, const float* records, const uint32_t* sorted_idx,
-                          const uint2* sorted_rect, const uint32_t* n_vis,
-                          const float* view_params, float* out_color, float* final_T,
-                          uint32_t* n_contrib, uint32_t* tile_end, hipStream_t st);
+void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,
+                      uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,
+                      hipStream_t st);
+void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
+                      const uint32_t* n_vis, uint32_t* counts, const uint32_t* tile_ranges,
+                      uint32_t* num_rendered, uint32_t* point_list, uint32_t capacity,
+                      hipStream_t st);
 
-void launch_export_bins(const PsRasterDesc& d, const uint32_t* sorted_idx,
-                        const uint2* sorted_rect, const uint32_t* n_vis, uint32_t* tile_counts,
-                        const uint32_t* tile_offsets, uint32_t* point_list, size_t capacity,
-                        hipStream_t st);
+void launch_tiles_forward(const PsRasterDesc& d, const float* records,
+                          const uint32_t* tile_ranges, const uint32_t* point_list,
+                          uint32_t capacity, const float* view_params, float* out_color,
+                          float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
+                          hipStream_t st);
 
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
-                           const uint32_t* sorted_idx, const uint2* sorted_rect,
-                           const float* view_params, const float* final_T,
+                           const uint32_t* tile_ranges, const uint32_t* point_list,
+                           uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const uint32_t* tile_end,
                            const float* dL_dcolor, float* grad2d, hipStream_t st);
 
@@ -123,6 +133,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ bool rect_covers(uint2 r, uint32_t tx, uint32_t ty) {
   const uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu, ymax = r.y >> 16;
   return (xmin <= tx) & (tx < xmax) & (ymin <= ty) & (ty < ymax);
+}
+
+// Same test in 4 integer ops (fields are < 2^15, so a borrow out of the low half only
+// happens when the low half already failed): precompute T = tx | ty << 16, T1 = T + 0x00010001.
+__device__ __forceinline__ bool rect_covers_packed(uint2 r, uint32_t T, uint32_t T1) {
+  return (((T - r.x) | (r.y - T1)) & 0x80008000u) == 0u;
 }
 
 }  // namespace ps

@@ -1,10 +1,19 @@
-// Tile kernels: one wave64 owns one 16x16 tile (4 pixels per lane: x = lane & 15,
-// y = (lane >> 4) + 4k).  There is no duplicated (tile, Gaussian) key list and no global
-// sort over it: the wave streams its view's depth-sorted rect array (L2 resident, 8 B per
-// Gaussian), keeps the entries whose rect covers the tile with ballot + popcount
-// compaction, stages the surviving records in LDS 64 at a time and alpha-composites them
-// front to back.  The sequence of survivors IS the reference's per-tile bin
-// (SURVEY.md A.2/A.3), in the same order.
+// Tile kernels: one wave64 owns one 16x16 tile, 4 pixels per lane -- pixel k of lane l sits
+// in 8x8 QUADRANT k at (l & 7, l >> 3).  Each staged entry carries a 4-bit mask of the
+// quadrants its alpha >= 1/255 ellipse can reach, so the per-entry work is skipped per
+// quadrant with wave-uniform (scalar) branches.  There is no duplicated (tile, Gaussian) key list and no global
+// sort over it.  Per tile the wave runs a two-stage, LDS-resident pipeline over its bin:
+//
+//   list     the tile's bin (raster_bins.hip): Gaussian ids in (depth, id) order, exactly
+//            the reference's per-tile range of its sorted point list; the
+//            1-based position in it is the "contributor" index n_contrib refers to.
+//   refine   64 list entries at a time, one per lane: gather the 48-byte record and test
+//            the alpha >= 1/255 ellipse against the tile's pixel box (exact conservative
+//            bound: the minimum of the quadratic form over the box).  Entries that cannot
+//            reach 1/255 on any pixel of the tile are dropped -- every pixel would have
+//            skipped them anyway (A.3), so results are unchanged -- survivors go to ring B
+//            with exp2-scaled conic coefficients.
+//   blend    64 ring-B entries at a time, broadcast from LDS, branch-free per-pixel update.
 //
 // Replaces renderCUDA fwd/bwd of the external rasterizer (call site
 // /root/reference/src/model/decoder/cuda_splatting.py:117-124).
@@ -12,24 +21,92 @@
 
 namespace ps {
 
-constexpr int kBatch = 64;         // entries blended per LDS stage
-constexpr int kQueue = 2 * kBatch; // compaction queue capacity (positions)
+constexpr int kBatch = 64;
+constexpr int kQB = 128;            // ring B capacity (>= 63 + 64), power of two
 constexpr int kWavesPerBlock = 4;
+constexpr float kLog2e = 1.4426950408889634f;
 
 struct WaveLds {
-  uint32_t queue[kQueue];
-  float4 rec[kBatch][3];
+  float4 rec[kQB][3];               // {gx,gy,A,B} {C,opacity,r,g} {b,list index,quad mask,id}
+};
+struct WaveLdsBwd : WaveLds {
+  float gsum[kBatch][kGradFloats + 1];  // per-entry reduced sums (+ "touched" flag)
 };
 
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
 __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
   return v;
+}
+
+// v_exp_f32: 2^x
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Conservative test: can alpha = opacity * exp(power) reach alpha_min on the box of pixel
+// centres [x0,x0+15] x [y0,y0+15]?  With A,B,C the log2-scaled coefficients
+// (power*log2e = A dx^2 + B dx dy + C dy^2, d = centre - pixel), Q = -(power*log2e) is a
+// convex quadratic for a positive-definite conic; its minimum over the box is 0 if the
+// centre is inside, else it lies on the (at most two) box edges facing the centre.
+__device__ __forceinline__ bool may_contribute(float gx, float gy, float A, float B, float Cq,
+                                               float opacity, float alpha_min, float x0,
+                                               float y0) {
+  const float tau = __log2f(opacity / alpha_min);   // need Q <= tau somewhere
+  if (!(tau >= 0.f)) return false;                  // opacity < alpha_min (or NaN): never
+  const float det = 4.f * A * Cq - B * B;
+  if (!(A < 0.f && Cq < 0.f && det > 0.f)) return true;  // not positive definite: keep
+  const float dxlo = gx - (x0 + 15.f), dxhi = gx - x0;   // range of dx over the box
+  const float dylo = gy - (y0 + 15.f), dyhi = gy - y0;
+  const float ex = dxlo > 0.f ? dxlo : (dxhi < 0.f ? dxhi : 0.f);  // nearest-edge offsets
+  const float ey = dylo > 0.f ? dylo : (dyhi < 0.f ? dyhi : 0.f);
+  if (ex == 0.f && ey == 0.f) return true;          // centre inside the box
+  float qmin = 3.0e38f;
+  if (ex != 0.f) {                                  // vertical edge dx = ex
+    const float dy = fminf(dyhi, fmaxf(dylo, -B * ex / (2.f * Cq)));
+    qmin = fminf(qmin, -(A * ex * ex + B * ex * dy + Cq * dy * dy));
+  }
+  if (ey != 0.f) {                                  // horizontal edge dy = ey
+    const float dx = fminf(dxhi, fmaxf(dxlo, -B * ey / (2.f * A)));
+    qmin = fminf(qmin, -(A * dx * dx + B * dx * ey + Cq * ey * ey));
+  }
+  // margin covers fp32 rounding of this bound and of the per-pixel power evaluation
+  return !(qmin > tau + 1e-4f * fabsf(tau) + 1e-3f);
+}
+
+// same bound on an (8+1)x(8+1) box of pixel centres [x0,x0+7] x [y0,y0+7] given tau
+__device__ __forceinline__ bool quad_may_contribute(float gx, float gy, float A, float B,
+                                                    float Cq, float tau, float x0, float y0) {
+  const float dxlo = gx - (x0 + 7.f), dxhi = gx - x0;
+  const float dylo = gy - (y0 + 7.f), dyhi = gy - y0;
+  const float ex = dxlo > 0.f ? dxlo : (dxhi < 0.f ? dxhi : 0.f);
+  const float ey = dylo > 0.f ? dylo : (dyhi < 0.f ? dyhi : 0.f);
+  if (ex == 0.f && ey == 0.f) return true;
+  float qmin = 3.0e38f;
+  if (ex != 0.f) {
+    const float dy = fminf(dyhi, fmaxf(dylo, -B * ex / (2.f * Cq)));
+    qmin = fminf(qmin, -(A * ex * ex + B * ex * dy + Cq * dy * dy));
+  }
+  if (ey != 0.f) {
+    const float dx = fminf(dxhi, fmaxf(dxlo, -B * ey / (2.f * A)));
+    qmin = fminf(qmin, -(A * dx * dx + B * dx * ey + Cq * ey * ey));
+  }
+  return !(qmin > tau + 1e-4f * fabsf(tau) + 1e-3f);
+}
+
+// 4-bit mask of the tile's 8x8 quadrants (bit k: x half = k & 1, y half = k >> 1) that the
+// entry can touch with alpha >= alpha_min; 0 = drop the entry.
+__device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, float B, float Cq,
+                                                  float opacity, float alpha_min, float x0,
+                                                  float y0) {
+  const float tau = __log2f(opacity / alpha_min);
+  if (!(tau >= 0.f)) return 0u;
+  const float det = 4.f * A * Cq - B * B;
+  if (!(A < 0.f && Cq < 0.f && det > 0.f)) return 0xFu;  // not positive definite: keep all
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (quad_may_contribute(gx, gy, A, B, Cq, tau, x0 + 8.f * (k & 1), y0 + 8.f * (k >> 1)))
+      m |= 1u << k;
+  return m;
 }
 
 // ------------------------------------------------------------------------------------
@@ -37,8 +114,8 @@ __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWavesPerBlock* kWave)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
-                     const uint32_t* __restrict__ sorted_idx,
-                     const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
+                     const uint32_t* __restrict__ tile_ranges,
+                     const uint32_t* __restrict__ point_list, uint32_t capacity,
                      const float* __restrict__ view_params, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                      uint32_t* __restrict__ tile_end) {
@@ -54,95 +131,91 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
   const size_t vo = (size_t)v * G;
-  const uint32_t n = n_vis[v];
-  const uint2* srect = sorted_rect + vo;
-  const uint32_t* sidx = sorted_idx + vo;
   const float* recs = records + vo * kRecFloats;
+  uint32_t l_start = tile_ranges[2 * (size_t)tile_global];
+  uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
+  if (l_start > capacity) l_start = capacity;                       // overflowed step: stay in
+  if (l_count > capacity - l_start) l_count = capacity - l_start;   // bounds (flag is raised)
+  const uint32_t* list = point_list + l_start;
 
-  const int px = tx * kTile + (lane & 15);
-  const float pxf = (float)px;
-  int py[4]; float pyf[4]; bool done[4];
+  const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
+  int px[4], py[4]; float pxf[4], pyf[4]; bool live[4];
   float T[4], C0[4], C1[4], C2[4]; uint32_t last[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    py[k] = ty * kTile + (lane >> 4) + 4 * k;
-    pyf[k] = (float)py[k];
-    done[k] = !(px < W && py[k] < H);
+    px[k] = tx * kTile + 8 * (k & 1) + (lane & 7);
+    py[k] = ty * kTile + 8 * (k >> 1) + (lane >> 3);
+    pxf[k] = (float)px[k]; pyf[k] = (float)py[k];
+    live[k] = px[k] < W && py[k] < H;
     T[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f; last[k] = 0;
   }
-  uint32_t last_pos = 0;       // sorted position + 1 of my latest contributor
-  uint32_t contributor = 0;    // wave-uniform count of list entries walked so far
-  uint32_t qn = 0;             // wave-uniform queue fill
+  uint32_t b_head = 0, b_tail = 0;  // wave-uniform ring cursors
   const uint64_t lt = lanemask_lt();
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min, t_min = d.t_min;
-  bool all_done = __all(done[0] & done[1] & done[2] & done[3]);
+  bool all_done = !__any(live[0] | live[1] | live[2] | live[3]);
 
-  auto process = [&](uint32_t m) {
-    // stage m records (lane j fetches entry j)
+  // refine list entries [first, first + m): lane i takes entry first + i
+  auto refine = [&](uint32_t first, uint32_t m) {
+    bool keep = false;
+    float4 q0, q1, q2;
     if ((uint32_t)lane < m) {
-      const uint32_t p = lds.queue[lane];
-      const uint32_t id = sidx[p];
+      const uint32_t id = list[first + lane];
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
-      float4 r0 = r[0], r1 = r[1], r2 = r[2];
-      r2.y = __uint_as_float(p);  // carry the sorted position in the (unused here) depth slot
-      lds.rec[lane][0] = r0; lds.rec[lane][1] = r1; lds.rec[lane][2] = r2;
+      const float4 r0 = r[0], r1 = r[1];
+      const float bch = recs[(size_t)id * kRecFloats + 8];
+      const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
+      const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
+      keep = qm != 0u;
+      q0 = make_float4(r0.x, r0.y, A, B);
+      q1 = make_float4(Cq, r1.y, r1.z, r1.w);
+      q2 = make_float4(bch, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
     }
-    wave_lds_sync();
-    for (uint32_t j = 0; j < m; ++j) {
-      const float4 r0 = lds.rec[j][0], r1 = lds.rec[j][1];
-      const float4 r2 = lds.rec[j][2];
-      contributor++;
-      const float gxp = r0.x, gyp = r0.y, cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
-      const float dx = gxp - pxf;
-      bool any_contrib = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dy = gyp - pyf[k];
-        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-        const float alpha = fminf(alpha_max, o * __expf(power));
-        const bool ok = !done[k] && power <= 0.f && alpha >= alpha_min;
-        if (ok) {
-          const float test_T = T[k] * (1.f - alpha);
-          if (test_T < t_min) {
-            done[k] = true;
-          } else {
-            const float wgt = alpha * T[k];
-            C0[k] += r1.z * wgt; C1[k] += r1.w * wgt; C2[k] += r2.x * wgt;
-            T[k] = test_T;
-            last[k] = contributor;
-            any_contrib = true;
-          }
-        }
-      }
-      if (any_contrib) last_pos = __float_as_uint(r2.y) + 1u;
-      if (__all(done[0] & done[1] & done[2] & done[3])) { all_done = true; break; }
+    const uint64_t mask = __ballot(keep);
+    if (keep) {
+      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
+      lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
     }
+    b_tail += (uint32_t)__popcll(mask);
     wave_lds_sync();
   };
 
-  for (uint32_t basep = 0; basep < n && !all_done; basep += kWave) {
-    const uint32_t p = basep + lane;
-    bool hit = false;
-    if (p < n) hit = rect_covers(srect[p], tx, ty);
-    const uint64_t mask = __ballot(hit);
-    if (mask != 0ull) {
-      if (hit) lds.queue[qn + (uint32_t)__popcll(mask & lt)] = p;
-      qn += (uint32_t)__popcll(mask);
-      wave_lds_sync();
-      if (qn >= (uint32_t)kBatch) {
-        process(kBatch);
-        // shift the remainder down
-        const uint32_t rem = qn - kBatch;
-        uint32_t tmp = 0;
-        if ((uint32_t)lane < rem) tmp = lds.queue[kBatch + lane];
-        wave_lds_sync();
-        if ((uint32_t)lane < rem) lds.queue[lane] = tmp;
-        wave_lds_sync();
-        qn = rem;
+  auto blend = [&](uint32_t m) {
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t slot = (b_head + j) & (kQB - 1);
+      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const uint32_t hidx = __float_as_uint(q2.y);
+      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
+          const float dx = q0.x - pxf[k], dy = q0.y - pyf[k];
+          const float pw = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), q1.x * dy * dy);  // power*log2e
+          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+          const bool ok = live[k] & (pw <= 0.f) & (alpha >= alpha_min);
+          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+          const float test_T = T[k] * (1.f - ale);
+          const bool stop = test_T < t_min;            // only possible when ale > 0
+          live[k] = live[k] & !stop;
+          const float wgt = stop ? 0.f : ale * T[k];
+          C0[k] = fmaf(q1.z, wgt, C0[k]);
+          C1[k] = fmaf(q1.w, wgt, C1[k]);
+          C2[k] = fmaf(q2.x, wgt, C2[k]);
+          T[k] = stop ? T[k] : test_T;
+          last[k] = (ok & !stop) ? hidx : last[k];
+        }
       }
+      if (!__any(live[0] | live[1] | live[2] | live[3])) { all_done = true; break; }
     }
+    b_head += m;
+    wave_lds_sync();
+  };
+
+  for (uint32_t first = 0; first < l_count && !all_done; first += kBatch) {
+    const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
+    refine(first, m);
+    while (!all_done && b_tail - b_head >= (uint32_t)kBatch) blend(kBatch);
   }
-  if (!all_done && qn > 0) process(qn);
+  if (!all_done && b_tail != b_head) blend(b_tail - b_head);
 
   // epilogue
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
@@ -151,8 +224,8 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   uint32_t max_c = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (px < W && py[k] < H) {
-      const size_t pix = (size_t)py[k] * W + px;
+    if (px[k] < W && py[k] < H) {
+      const size_t pix = (size_t)py[k] * W + px[k];
       float* oc = out_color + (size_t)v * 3 * P;
       oc[pix] = C0[k] + T[k] * bg0;
       oc[P + pix] = C1[k] + T[k] * bg1;
@@ -163,89 +236,49 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     }
   }
   max_c = wave_max_u(max_c);
-  const uint32_t max_p = wave_max_u(last_pos);
-  if (lane == 0) {
-    tile_end[2 * (size_t)tile_global] = max_c;
-    tile_end[2 * (size_t)tile_global + 1] = max_p;
-  }
+  if (lane == 0) tile_end[tile_global] = max_c;
 }
 
-void launch_tiles_forward(const PsRasterDesc& d, const float* records, const uint32_t* sorted_idx,
-                          const uint2* sorted_rect, const uint32_t* n_vis,
-                          const float* view_params, float* out_color, float* final_T,
-                          uint32_t* n_contrib, uint32_t* tile_end, hipStream_t st) {
+void launch_tiles_forward(const PsRasterDesc& d, const float* records,
+                          const uint32_t* tile_ranges, const uint32_t* point_list,
+                          uint32_t capacity, const float* view_params, float* out_color,
+                          float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
+                          hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, sorted_idx,
-                     sorted_rect, n_vis, view_params, out_color, final_T, n_contrib, tile_end);
-}
-
-// ------------------------------------------------------------------------------------
-// parity export of the bins (tests only; not on the training path)
-// ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWavesPerBlock* kWave)
-export_bins_kernel(PsRasterDesc d, const uint32_t* __restrict__ sorted_idx,
-                   const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
-                   uint32_t* __restrict__ tile_counts, const uint32_t* __restrict__ tile_offsets,
-                   uint32_t* __restrict__ point_list, size_t capacity) {
-  const int G = d.n_gaussians;
-  const int gx = (d.width + kTile - 1) / kTile, gy = (d.height + kTile - 1) / kTile;
-  const int tiles = gx * gy;
-  const int V = d.n_scenes * d.views_per_scene;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile_global = blockIdx.x * kWavesPerBlock + w;
-  if (tile_global >= V * tiles) return;
-  const int v = tile_global / tiles, t = tile_global % tiles;
-  const uint32_t tx = t % gx, ty = t / gx;
-  const size_t vo = (size_t)v * G;
-  const uint32_t n = n_vis[v];
-  const uint64_t lt = lanemask_lt();
-  uint32_t count = 0;
-  const size_t off = (point_list && tile_offsets) ? tile_offsets[tile_global] : 0;
-  for (uint32_t basep = 0; basep < n; basep += kWave) {
-    const uint32_t p = basep + lane;
-    bool hit = false;
-    if (p < n) hit = rect_covers(sorted_rect[vo + p], tx, ty);
-    const uint64_t mask = __ballot(hit);
-    if (hit && point_list) {
-      const size_t q = off + count + (uint32_t)__popcll(mask & lt);
-      if (q < capacity) point_list[q] = sorted_idx[vo + p];
-    }
-    count += (uint32_t)__popcll(mask);
-  }
-  if (lane == 0 && tile_counts) tile_counts[tile_global] = count;
-}
-
-void launch_export_bins(const PsRasterDesc& d, const uint32_t* sorted_idx,
-                        const uint2* sorted_rect, const uint32_t* n_vis, uint32_t* tile_counts,
-                        const uint32_t* tile_offsets, uint32_t* point_list, size_t capacity,
-                        hipStream_t st) {
-  const Dims m = make_dims(d);
-  const int total = m.V * m.tiles;
-  dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(export_bins_kernel, grid, block, 0, st, d, sorted_idx, sorted_rect, n_vis,
-                     tile_counts, tile_offsets, point_list, capacity);
+  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_ranges,
+                     point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
 }
 
 // ------------------------------------------------------------------------------------
 // backward: walk the tile's bin back to front from the last contributor
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Wave64 sum by DPP (one fused shift+add per step); the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);  // row_shr:8  -> lane 15 of each row holds the row total
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
   return v;
 }
 
 __global__ void __launch_bounds__(kWavesPerBlock* kWave)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
-                      const uint32_t* __restrict__ sorted_idx,
-                      const uint2* __restrict__ sorted_rect,
+                      const uint32_t* __restrict__ tile_ranges,
+                      const uint32_t* __restrict__ point_list, uint32_t capacity,
                       const float* __restrict__ view_params, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib,
                       const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
                       float* __restrict__ grad2d) {
-  __shared__ WaveLds lds_all[kWavesPerBlock];
+  __shared__ WaveLdsBwd lds_all[kWavesPerBlock];
   const int G = d.n_gaussians, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
   const int tiles = gx * gy;
@@ -253,154 +286,178 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile_global = blockIdx.x * kWavesPerBlock + w;
   if (tile_global >= V * tiles) return;
-  WaveLds& lds = lds_all[w];
+  WaveLdsBwd& lds = lds_all[w];
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
   const size_t vo = (size_t)v * G;
-  const uint2* srect = sorted_rect + vo;
-  const uint32_t* sidx = sorted_idx + vo;
   const float* recs = records + vo * kRecFloats;
   float* gacc = grad2d + vo * kGradFloats;
+  uint32_t l_start = tile_ranges[2 * (size_t)tile_global];
+  if (l_start > capacity) l_start = capacity;
+  const uint32_t* list = point_list + l_start;
 
-  const uint32_t c_max = tile_end[2 * (size_t)tile_global];
-  const uint32_t p_end = tile_end[2 * (size_t)tile_global + 1];  // position + 1
+  // entries behind the tile's last contributor are never touched (1-based index c_max)
+  const uint32_t c_max = tile_end[tile_global];
   if (c_max == 0) return;
 
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t P = (size_t)H * W;
-  const int px = tx * kTile + (lane & 15);
-  const float pxf = (float)px;
-  float pyf[4], T[4], Tfin[4], g0[4], g1[4], g2[4], bgdot[4];
-  float acc0[4], acc1[4], acc2[4], last_alpha[4], lc0[4], lc1[4], lc2[4];
+  const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
+  float pxf[4], pyf[4], T[4], Tfb[4], g0[4], g1[4], g2[4], acc0[4], acc1[4], acc2[4];
   uint32_t nc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int py = ty * kTile + (lane >> 4) + 4 * k;
-    pyf[k] = (float)py;
+    const int px = tx * kTile + 8 * (k & 1) + (lane & 7);
+    const int py = ty * kTile + 8 * (k >> 1) + (lane >> 3);
+    pxf[k] = (float)px; pyf[k] = (float)py;
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)py * W + px : 0;
     nc[k] = inside ? n_contrib[(size_t)v * P + pix] : 0u;
-    Tfin[k] = inside ? final_T[(size_t)v * P + pix] : 0.f;
-    T[k] = Tfin[k];
+    T[k] = inside ? final_T[(size_t)v * P + pix] : 0.f;
     const float* gp = dL_dcolor + (size_t)v * 3 * P;
     g0[k] = inside ? gp[pix] : 0.f;
     g1[k] = inside ? gp[P + pix] : 0.f;
     g2[k] = inside ? gp[2 * P + pix] : 0.f;
-    bgdot[k] = bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k];
-    acc0[k] = acc1[k] = acc2[k] = 0.f; last_alpha[k] = 0.f; lc0[k] = lc1[k] = lc2[k] = 0.f;
+    Tfb[k] = -T[k] * (bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k]);  // -T_final * (bg . dL/dC)
+    acc0[k] = acc1[k] = acc2[k] = 0.f;   // colour composited BEHIND the current entry
   }
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
   const uint64_t lt = lanemask_lt();
-  uint32_t c_run = c_max;  // 1-based list index of the next entry to process
-  uint32_t qn = 0;
+  uint32_t b_head = 0, b_tail = 0;
 
-  auto process = [&](uint32_t m) {
-    uint32_t my_id = 0;
+  // refine list entries with 1-based indices top, top-1, ..., top-m+1 (lane i takes top - i)
+  auto refine = [&](uint32_t top, uint32_t m) {
+    bool keep = false;
+    float4 q0, q1, q2;
     if ((uint32_t)lane < m) {
-      const uint32_t p = lds.queue[lane];
-      my_id = sidx[p];
-      const float4* r = reinterpret_cast<const float4*>(recs + (size_t)my_id * kRecFloats);
-      lds.rec[lane][0] = r[0]; lds.rec[lane][1] = r[1]; lds.rec[lane][2] = r[2];
+      const uint32_t id = list[top - 1u - lane];
+      const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
+      const float4 r0 = r[0], r1 = r[1];
+      const float bch = recs[(size_t)id * kRecFloats + 8];
+      const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
+      const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
+      keep = qm != 0u;
+      q0 = make_float4(r0.x, r0.y, A, B);
+      q1 = make_float4(Cq, r1.y, r1.z, r1.w);
+      q2 = make_float4(bch, __uint_as_float(top - lane), __uint_as_float(qm),
+                       __uint_as_float(id));
     }
-    wave_lds_sync();
-    for (uint32_t j = 0; j < m; ++j) {
-      const uint32_t cidx = c_run - j;  // >= 1
-      const float4 r0 = lds.rec[j][0], r1 = lds.rec[j][1];
-      const float4 r2 = lds.rec[j][2];
-      const float gxp = r0.x, gyp = r0.y, cx = r0.z, cy = r0.w, cz = r1.x, o = r1.y;
-      const float c0 = r1.z, c1 = r1.w, c2 = r2.x;
-      const float dx = gxp - pxf;
-      float s_dx = 0.f, s_dy = 0.f, s_ca = 0.f, s_cb = 0.f, s_cc = 0.f, s_op = 0.f;
-      float s_r = 0.f, s_g = 0.f, s_b = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dy = gyp - pyf[k];
-        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-        const float Gv = __expf(power);
-        const float alpha = fminf(alpha_max, o * Gv);
-        const bool ok = (cidx <= nc[k]) && power <= 0.f && alpha >= alpha_min;
-        if (ok) {
-          any = true;
-          T[k] = T[k] / (1.f - alpha);
-          const float dch = alpha * T[k];
-          acc0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * acc0[k]; lc0[k] = c0;
-          acc1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * acc1[k]; lc1[k] = c1;
-          acc2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * acc2[k]; lc2[k] = c2;
-          float dL_dalpha = (c0 - acc0[k]) * g0[k] + (c1 - acc1[k]) * g1[k] +
-                            (c2 - acc2[k]) * g2[k];
-          s_r += dch * g0[k]; s_g += dch * g1[k]; s_b += dch * g2[k];
-          dL_dalpha *= T[k];
-          last_alpha[k] = alpha;
-          dL_dalpha += (-Tfin[k] / (1.f - alpha)) * bgdot[k];
-          const float dL_dG = o * dL_dalpha;
-          const float gdx = Gv * dx, gdy = Gv * dy;
-          s_dx += dL_dG * (-gdx * cx - gdy * cy);
-          s_dy += dL_dG * (-gdy * cz - gdx * cy);
-          s_ca += -0.5f * gdx * dx * dL_dG;
-          s_cb += -0.5f * gdx * dy * dL_dG;
-          s_cc += -0.5f * gdy * dy * dL_dG;
-          s_op += Gv * dL_dalpha;
-        }
-      }
-      if (__any(any)) {
-        s_dx = wave_sum(s_dx) * ddelx_dx; s_dy = wave_sum(s_dy) * ddely_dy;
-        s_ca = wave_sum(s_ca); s_cb = wave_sum(s_cb); s_cc = wave_sum(s_cc);
-        s_op = wave_sum(s_op);
-        s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b);
-        // lane q (< 9) owns component q of entry j
-        float mine = s_dx;
-        mine = lane == 1 ? s_dy : mine; mine = lane == 2 ? s_ca : mine;
-        mine = lane == 3 ? s_cb : mine; mine = lane == 4 ? s_cc : mine;
-        mine = lane == 5 ? s_op : mine; mine = lane == 6 ? s_r : mine;
-        mine = lane == 7 ? s_g : mine;  mine = lane == 8 ? s_b : mine;
-        const uint32_t id = __shfl(my_id, (int)j);
-        if (lane < kGradFloats) atomicAdd(gacc + (size_t)id * kGradFloats + lane, mine);
-      }
+    const uint64_t mask = __ballot(keep);
+    if (keep) {
+      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
+      lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
     }
-    c_run -= m;
+    b_tail += (uint32_t)__popcll(mask);
     wave_lds_sync();
   };
 
-  // stream positions p_end-1 ... 0 in descending order; lane 0 takes the highest
-  for (uint32_t top = p_end; top > 0 && c_run > 0;) {
-    const bool in = (uint32_t)lane < top;
-    const uint32_t p = in ? top - 1u - lane : 0u;
-    bool hit = false;
-    if (in) hit = rect_covers(srect[p], tx, ty);
-    const uint64_t mask = __ballot(hit);
-    if (mask != 0ull) {
-      if (hit) lds.queue[qn + (uint32_t)__popcll(mask & lt)] = p;
-      qn += (uint32_t)__popcll(mask);
-      wave_lds_sync();
-      if (qn >= (uint32_t)kBatch) {
-        process(kBatch);
-        const uint32_t rem = qn - kBatch;
-        uint32_t tmp = 0;
-        if ((uint32_t)lane < rem) tmp = lds.queue[kBatch + lane];
-        wave_lds_sync();
-        if ((uint32_t)lane < rem) lds.queue[lane] = tmp;
-        wave_lds_sync();
-        qn = rem;
+  auto blend = [&](uint32_t m) {
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t slot = (b_head + j) & (kQB - 1);
+      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
+      const uint32_t hidx = __float_as_uint(q2.y);
+      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+      float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
+      float s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (qm & (1u << k)) {   // wave-uniform quadrant skip
+          const float dx = q0.x - pxf[k], dy = q0.y - pyf[k];
+          const float pw = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), q1.x * dy * dy);
+          const float Gv = fast_exp2(pw);
+          const float alpha = fminf(alpha_max, o * Gv);
+          const bool ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
+          const float ale = ok ? alpha : 0.f;              // 0 => all updates are no-ops
+          const float oma = 1.f - ale;
+          float rcp = __builtin_amdgcn_rcpf(oma);
+          rcp = fmaf(fmaf(-oma, rcp, 1.f), rcp, rcp);      // one Newton step: ~0.5 ulp
+          const float Tn = T[k] * rcp;                      // T in front of this entry
+          const float d0 = c0 - acc0[k], d1 = c1 - acc1[k], d2 = c2 - acc2[k];
+          float dL_dalpha = (d0 * g0[k] + d1 * g1[k] + d2 * g2[k]) * Tn;
+          dL_dalpha = fmaf(Tfb[k], rcp, dL_dalpha);         // -T_final/(1-alpha) * bg.dL/dC
+          const float dch = ale * Tn;
+          s_r = fmaf(dch, g0[k], s_r); s_g = fmaf(dch, g1[k], s_g); s_b = fmaf(dch, g2[k], s_b);
+          const float gda = ok ? Gv * dL_dalpha : 0.f;      // G * dL/dalpha
+          s_op += gda;
+          const float q = o * gda;                          // G * dL/dG
+          const float qx = q * dx, qy = q * dy;
+          Mx += qx; My += qy;
+          Mxx = fmaf(qx, dx, Mxx); Mxy = fmaf(qx, dy, Mxy); Myy = fmaf(qy, dy, Myy);
+          T[k] = Tn;
+          acc0[k] = fmaf(ale, d0, acc0[k]);                 // alpha c + (1 - alpha) acc
+          acc1[k] = fmaf(ale, d1, acc1[k]);
+          acc2[k] = fmaf(ale, d2, acc2[k]);
+          any |= ok;
+        }
+      }
+      if (__any(any)) {
+        // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
+        Mx = wave_sum_to_lane63(Mx);
+        My = wave_sum_to_lane63(My);
+        Mxx = wave_sum_to_lane63(Mxx);
+        Mxy = wave_sum_to_lane63(Mxy);
+        Myy = wave_sum_to_lane63(Myy);
+        const float sop = wave_sum_to_lane63(s_op);
+        const float sr = wave_sum_to_lane63(s_r);
+        const float sg = wave_sum_to_lane63(s_g);
+        const float sb = wave_sum_to_lane63(s_b);
+        if (lane == 63) {
+          float* gs = lds.gsum[j];
+          gs[0] = Mx; gs[1] = My; gs[2] = Mxx; gs[3] = Mxy; gs[4] = Myy; gs[5] = sop;
+          gs[6] = sr; gs[7] = sg; gs[8] = sb; gs[9] = 1.f;
+        }
+      } else if (lane == 63) {
+        lds.gsum[j][9] = 0.f;
       }
     }
-    top = top > (uint32_t)kWave ? top - kWave : 0u;
+    wave_lds_sync();
+    // lane j finalises entry j: one set of 9 atomics per (tile, Gaussian)
+    if ((uint32_t)lane < m && lds.gsum[lane][9] != 0.f) {
+      const uint32_t slot = (b_head + lane) & (kQB - 1);
+      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const float* gs = lds.gsum[lane];
+      const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
+                  cz = q1.x * (-2.f / kLog2e);
+      const float Mx = gs[0], My = gs[1];
+      float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
+      atomicAdd(ga + 0, (-cx * Mx - cy * My) * ddelx_dx);
+      atomicAdd(ga + 1, (-cz * My - cy * Mx) * ddely_dy);
+      atomicAdd(ga + 2, -0.5f * gs[2]);
+      atomicAdd(ga + 3, -0.5f * gs[3]);
+      atomicAdd(ga + 4, -0.5f * gs[4]);
+      atomicAdd(ga + 5, gs[5]);
+      atomicAdd(ga + 6, gs[6]);
+      atomicAdd(ga + 7, gs[7]);
+      atomicAdd(ga + 8, gs[8]);
+    }
+    b_head += m;
+    wave_lds_sync();
+  };
+
+  for (uint32_t top = c_max; top > 0;) {
+    const uint32_t m = top < (uint32_t)kBatch ? top : (uint32_t)kBatch;
+    refine(top, m);
+    while (b_tail - b_head >= (uint32_t)kBatch) blend(kBatch);
+    top -= m;
   }
-  if (qn > 0 && c_run > 0) process(qn < c_run ? qn : c_run);
+  if (b_tail != b_head) blend(b_tail - b_head);
 }
 
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
-                           const uint32_t* sorted_idx, const uint2* sorted_rect,
-                           const float* view_params, const float* final_T,
+                           const uint32_t* tile_ranges, const uint32_t* point_list,
+                           uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const uint32_t* tile_end,
                            const float* dL_dcolor, float* grad2d, hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, sorted_idx,
-                     sorted_rect, view_params, final_T, n_contrib, tile_end, dL_dcolor, grad2d);
+  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_ranges,
+                     point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
+                     grad2d);
 }
 
 }  // namespace ps

@@ -69,11 +69,12 @@ def _render(extrinsics, near, far, fov_x, fov_y, tan_fov, image_shape, backgroun
                                  vp, sh=sh, colors=colors)
         # second (no-grad) pass only to expose the saved state to tests
         with torch.no_grad():
-            _, _, state, lay = forward_with_state(
+            res, lay = forward_with_state(
                 cfg, gaussian_means.detach(), gaussian_covariances.detach(),
                 gaussian_opacities.detach(), vp, sh=None if sh is None else sh.detach(),
                 colors=None if colors is None else colors.detach())
-        return image, dict(cfg=cfg, radii=radii, state=state, layout=lay, view_params=vp)
+        return image, dict(cfg=cfg, radii=radii, state=res.state, layout=lay, view_params=vp,
+                           point_list=res.point_list, num_rendered=res.num_rendered)
     image, _ = rasterize(cfg, gaussian_means, gaussian_covariances, gaussian_opacities, vp,
                          sh=sh, colors=colors)
     return image

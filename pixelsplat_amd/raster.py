@@ -6,8 +6,12 @@ arithmetic happens in libpixelsplat_hip.so; there is no fallback path.
 `rasterize(...)` is the batched operator (S scenes x views_per_scene views in one call).
 It replaces, per call, the whole loop of
 /root/reference/src/model/decoder/cuda_splatting.py:91-126 (B sequential
-`GaussianRasterizer` invocations with host syncs) and the v-fold `repeat` of
+`GaussianRasterizer` invocations, three host syncs each) and the v-fold `repeat` of
 /root/reference/src/model/decoder/decoder_splatting_cuda.py:53-56.
+
+Host syncs per call: ONE 8-byte read-back of D (the total tile-list length, which sizes the
+point list exactly) -- or ZERO when `RasterConfig.list_capacity` fixes the capacity up front;
+an overflow is then detected asynchronously and raised from backward().
 """
 from __future__ import annotations
 
@@ -51,6 +55,9 @@ class RasterConfig:
     sh_coeffs: int
     sh_layout: int = PS_SH_GK3
     cov_layout: int = PS_COV_6
+    # 0: size the tile point list exactly (one 8-byte host read-back per call);
+    # > 0: fixed capacity in entries, no host sync, overflow raises from backward()
+    list_capacity: int = 0
 
     def desc(self) -> _lib.PsRasterDesc:
         d = _lib.default_desc()
@@ -60,6 +67,14 @@ class RasterConfig:
         d.sh_degree, d.sh_coeffs = self.sh_degree, self.sh_coeffs
         d.sh_layout, d.cov_layout = self.sh_layout, self.cov_layout
         return d
+
+    @property
+    def n_views(self) -> int:
+        return self.n_scenes * self.views_per_scene
+
+    @property
+    def n_tiles(self) -> int:
+        return ((self.width + 15) // 16) * ((self.height + 15) // 16)
 
 
 def _p(t: Tensor | None):
@@ -81,40 +96,85 @@ def _check_dev(*ts):
             raise RuntimeError(f"expected float32 tensors, got {t.dtype}")
 
 
+@dataclass
+class ForwardResult:
+    color: Tensor
+    radii: Tensor
+    state: Tensor             # uint8, layout = ps_raster_state_layout
+    point_list: Tensor        # int32 [capacity]
+    num_rendered: int | None  # D when it was read back (exact-size mode), else None
+    overflow_host: Tensor | None = None
+    overflow_event: object | None = None
+
+
+def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params) -> ForwardResult:
+    lib = _lib.load()
+    d = cfg.desc()
+    V, dev = cfg.n_views, means.device
+    color = torch.empty((V, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, cfg.n_gaussians), dtype=torch.int32, device=dev)
+    state = torch.empty(lib.ps_raster_state_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    if cfg.list_capacity > 0:
+        plist = torch.empty(cfg.list_capacity, dtype=torch.int32, device=dev)
+        _lib.check(lib.ps_raster_forward(
+            C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
+            _p(color), _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist),
+            plist.numel(), _stream()), "ps_raster_forward")
+        lay = _lib.PsRasterStateLayout()
+        lib.ps_raster_state_layout(C.byref(d), C.byref(lay))
+        flag = torch.empty(2, dtype=torch.int32, pin_memory=True)  # caching host allocator
+        flag.copy_(state[lay.num_rendered:lay.num_rendered + 8].view(torch.int32),
+                   non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ForwardResult(color, radii, state, plist, None, flag, ev)
+    _lib.check(lib.ps_raster_forward_plan(
+        C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
+        _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _stream()),
+        "ps_raster_forward_plan")
+    n = C.c_uint64(0)
+    _lib.check(lib.ps_raster_check(C.byref(d), _p(state), state.numel(), C.byref(n), _stream()),
+               "ps_raster_check")
+    plist = torch.empty(max(int(n.value), 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.ps_raster_forward_render(
+        C.byref(d), _p(view_params), _p(color), _p(state), state.numel(), _p(temp), temp.numel(),
+        _p(plist), int(n.value), _stream()), "ps_raster_forward_render")
+    return ForwardResult(color, radii, state, plist, int(n.value))
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: RasterConfig, means, cov, opacity, sh, colors, view_params, means2d):
-        lib = _lib.load()
         _check_dev(means, cov, opacity, sh, colors, view_params)
         means, cov, opacity = means.contiguous(), cov.contiguous(), opacity.contiguous()
         sh = None if sh is None else sh.contiguous()
         colors = None if colors is None else colors.contiguous()
         view_params = view_params.contiguous()
-        d = cfg.desc()
-        V = cfg.n_scenes * cfg.views_per_scene
-        dev = means.device
-        color = torch.empty((V, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
-        radii = torch.empty((V, cfg.n_gaussians), dtype=torch.int32, device=dev)
-        state = torch.empty(lib.ps_raster_state_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
-        temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
-        _lib.check(lib.ps_raster_forward(
-            C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
-            _p(color), _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _stream()),
-            "ps_raster_forward")
+        r = _forward(cfg, means, cov, opacity, sh, colors, view_params)
         ctx.cfg = cfg
         ctx.has_means2d = means2d is not None
-        ctx.save_for_backward(means, cov, opacity, sh, colors, view_params, radii, state)
-        ctx.mark_non_differentiable(radii)
-        return color, radii
+        ctx.overflow = (r.overflow_host, r.overflow_event)
+        ctx.save_for_backward(means, cov, opacity, sh, colors, view_params, r.radii, r.state,
+                              r.point_list)
+        ctx.mark_non_differentiable(r.radii)
+        return r.color, r.radii
 
     @staticmethod
     def backward(ctx, dL_dcolor, _dradii):
         lib = _lib.load()
         cfg: RasterConfig = ctx.cfg
-        means, cov, opacity, sh, colors, view_params, radii, state = ctx.saved_tensors
+        means, cov, opacity, sh, colors, view_params, radii, state, plist = ctx.saved_tensors
         d = cfg.desc()
-        V = cfg.n_scenes * cfg.views_per_scene
-        dev = means.device
+        V, dev = cfg.n_views, means.device
+        flag, ev = ctx.overflow
+        if flag is not None:
+            ev.synchronize()  # long complete: the copy was queued right after the forward
+            if int(flag[1]) != 0:
+                raise RuntimeError(
+                    f"pixelsplat_amd.rasterize: {int(flag[0])} tile-list entries exceed "
+                    f"list_capacity={cfg.list_capacity} (PS_ERR_CAPACITY); raise it or use "
+                    f"list_capacity=0 (exact sizing)")
         dL_dcolor = dL_dcolor.contiguous()
         g_means = torch.empty_like(means)
         g_cov = torch.empty_like(cov)
@@ -127,14 +187,14 @@ class _Rasterize(torch.autograd.Function):
         _lib.check(lib.ps_raster_backward(
             C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
             _p(radii), _p(dL_dcolor), _p(state), state.numel(), _p(temp), temp.numel(),
-            _p(g_means), _p(g_cov), _p(g_sh), _p(g_colors), _p(g_op), _p(g_m2d), _stream()),
-            "ps_raster_backward")
+            _p(plist), plist.numel(), _p(g_means), _p(g_cov), _p(g_sh), _p(g_colors), _p(g_op),
+            _p(g_m2d), _stream()), "ps_raster_backward")
         return None, g_means, g_cov, g_op, g_sh, g_colors, None, g_m2d
 
 
 def rasterize(cfg: RasterConfig, means: Tensor, cov: Tensor, opacity: Tensor,
               view_params: Tensor, sh: Tensor | None = None, colors: Tensor | None = None,
-              means2d: Tensor | None = None, return_state: bool = False):
+              means2d: Tensor | None = None):
     """Batched differentiable 3-D Gaussian rasterization on the HIP kernels.
 
     means [S,G,3]; cov [S,G,6] | [S,G,3,3]; opacity [S,G]; view_params [V,48] (see
@@ -147,32 +207,21 @@ def rasterize(cfg: RasterConfig, means: Tensor, cov: Tensor, opacity: Tensor,
     return _Rasterize.apply(cfg, means, cov, opacity, sh, colors, view_params, means2d)
 
 
-# ---- debug / parity helpers (used by tests; thin views over the saved state) --------------
+# ---- debug / parity helpers (used by tests and bench; thin views over the saved state) ----
 def forward_with_state(cfg: RasterConfig, means, cov, opacity, view_params, sh=None, colors=None):
-    """Runs the forward kernels and returns (color, radii, state bytes tensor, layout)."""
+    """Runs the forward kernels (no autograd) and returns (ForwardResult, state layout)."""
     lib = _lib.load()
+    r = _forward(cfg, means.contiguous(), cov.contiguous(), opacity.contiguous(),
+                 None if sh is None else sh.contiguous(),
+                 None if colors is None else colors.contiguous(), view_params.contiguous())
     d = cfg.desc()
-    V = cfg.n_scenes * cfg.views_per_scene
-    dev = means.device
-    color = torch.empty((V, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
-    radii = torch.empty((V, cfg.n_gaussians), dtype=torch.int32, device=dev)
-    state = torch.zeros(lib.ps_raster_state_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
-    temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
-    _lib.check(lib.ps_raster_forward(
-        C.byref(d), _p(means.contiguous()), _p(cov.contiguous()),
-        _p(None if sh is None else sh.contiguous()),
-        _p(None if colors is None else colors.contiguous()), _p(opacity.contiguous()),
-        _p(view_params.contiguous()), _p(color), _p(radii), _p(state), state.numel(), _p(temp),
-        temp.numel(), _stream()), "ps_raster_forward")
     lay = _lib.PsRasterStateLayout()
     _lib.check(lib.ps_raster_state_layout(C.byref(d), C.byref(lay)), "ps_raster_state_layout")
-    return color, radii, state, lay
+    return r, lay
 
 
 def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
-    V = cfg.n_scenes * cfg.views_per_scene
-    G, P = cfg.n_gaussians, cfg.height * cfg.width
-    tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
+    V, G, P, tiles = cfg.n_views, cfg.n_gaussians, cfg.height * cfg.width, cfg.n_tiles
     N = V * G
 
     def view(off, nbytes, dtype, shape):
@@ -186,25 +235,17 @@ def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
         n_vis=view(lay.n_vis, V * 4, torch.int32, (V,)),
         final_T=view(lay.final_T, V * P * 4, torch.float32, (V, P)),
         n_contrib=view(lay.n_contrib, V * P * 4, torch.int32, (V, P)),
-        tile_end=view(lay.tile_end, V * tiles * 8, torch.int32, (V, tiles, 2)),
+        tile_end=view(lay.tile_end, V * tiles * 4, torch.int32, (V, tiles)),
+        tile_ranges=view(lay.tile_ranges, V * tiles * 8, torch.int32, (V, tiles, 2)),
+        num_rendered=view(lay.num_rendered, 8, torch.int32, (2,)),
     )
 
 
-def export_bins(cfg: RasterConfig, state: Tensor):
-    """(tile_counts [V,T] int32, point_list int32[D]) -- the bins the tile kernels walk, in
-    blend order; bit-exact counterpart of the reference's sorted point list + ranges."""
-    lib = _lib.load()
-    d = cfg.desc()
-    V = cfg.n_scenes * cfg.views_per_scene
-    tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
-    counts = torch.zeros((V, tiles), dtype=torch.int32, device=state.device)
-    _lib.check(lib.ps_raster_export_bins(C.byref(d), _p(state), state.numel(), _p(counts), None,
-                                         None, 0, _stream()), "ps_raster_export_bins")
-    flat = counts.reshape(-1).to(torch.int64)
-    offsets = (torch.cumsum(flat, 0) - flat).to(torch.int32)
-    total = int(flat.sum().item())
-    plist = torch.zeros(max(total, 1), dtype=torch.int32, device=state.device)
-    _lib.check(lib.ps_raster_export_bins(C.byref(d), _p(state), state.numel(), _p(counts),
-                                         _p(offsets), _p(plist), total, _stream()),
-               "ps_raster_export_bins")
-    return counts, offsets.reshape(V, tiles), plist[:total]
+def export_bins(cfg: RasterConfig, state: Tensor, lay, point_list: Tensor):
+    """(tile_counts [V,T], tile_offsets [V,T], point_list int32[D]) -- the bins the tile
+    kernels walk, in blend order; bit-exact counterpart of the reference's sorted point
+    list + tile ranges."""
+    sv = state_views(cfg, state, lay)
+    ranges = sv["tile_ranges"]
+    n = int(sv["num_rendered"][0].item())
+    return ranges[..., 1].contiguous(), ranges[..., 0].contiguous(), point_list[:n]

@@ -44,7 +44,7 @@ def test_desc_defaults_and_sizes(lib):
     lay = _lib.PsRasterStateLayout()
     assert lib.ps_raster_state_layout(C.byref(d), C.byref(lay)) == 0
     offs = [lay.records, lay.rects, lay.sorted_idx, lay.sorted_rect, lay.n_vis, lay.final_T,
-            lay.n_contrib, lay.tile_end, lay.total]
+            lay.n_contrib, lay.tile_end, lay.tile_ranges, lay.num_rendered, lay.total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
 
 
@@ -53,12 +53,12 @@ def test_bad_arguments_are_status_codes_not_crashes(lib):
     d = _lib.default_desc()
     d.n_gaussians, d.height, d.width = 16, 32, 32
     rc = lib.ps_raster_forward(C.byref(d), None, None, None, None, None, None, None, None, None,
-                               0, None, 0, None)
+                               0, None, 0, None, 0, None)
     assert rc == -1
     assert b"bad argument" in lib.ps_status_string(rc)
     with pytest.raises(RuntimeError):
         _lib.check(rc, "ps_raster_forward")
-    assert lib.ps_raster_export_bins(C.byref(d), None, 0, None, None, None, 0, None) == -1
+    assert lib.ps_raster_check(C.byref(d), None, 0, None, None) == -1
     assert lib.ps_profile_group_count() >= 5
 
 
