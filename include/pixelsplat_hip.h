@@ -84,7 +84,7 @@ typedef struct PsRasterDesc {
 /* byte offsets of the arrays inside the `state` buffer (for tests / debugging).
  * V = n_scenes*views_per_scene, N = V*G, P = H*W, T = tiles per view. */
 typedef struct PsRasterStateLayout {
-  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,r,g | b,depth,radius(i32),clamp bits */
+  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,depth,radius(i32) | r,g,b,clamp bits */
   size_t rects;       /* uint16[N][4]: tile rect xmin,ymin,xmax,ymax                   */
   size_t sorted_idx;  /* uint32[N]: per view, Gaussian ids in (depth, id) order; first n_vis valid */
   size_t sorted_rect; /* uint16[N][4]: rects permuted into sorted order                */

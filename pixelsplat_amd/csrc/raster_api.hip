@@ -118,13 +118,9 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   hipStream_t st = (hipStream_t)stream;
   const FwdPtrs p = fwd_ptrs(*d, state, temp);
   {
-    Scope sc(G_MEMSET, st);
-    if (hipMemsetAsync(p.n_vis, 0, (size_t)m.V * 4, st) != hipSuccess) return PS_ERR_LAUNCH;
-  }
-  {
     Scope sc(G_PRE_FWD, st);
     launch_preprocess_forward(*d, means, cov, sh, colors, opacity, view_params, p.records,
-                              p.keys_a, p.rects, out_radii, p.n_vis, st);
+                              p.keys_a, p.rects, out_radii, st);
   }
   {
     Scope sc(G_SORT, st);

@@ -1,8 +1,14 @@
 // Preprocess backward: screen-space gradients (dxy in NDC units, dconic, dopacity, drgb
 // accumulated per (view, Gaussian) by the tile backward) -> dL/d{means, cov, SH|colors,
-// opacity}.  One thread per scene Gaussian, looping over the scene's views and summing in
-// registers: each output is written once, without atomics, and the v-fold `repeat`
-// backward of decoder_splatting_cuda.py:53-56 never materialises.
+// opacity}.  Two kernels, both one thread per scene Gaussian looping over the scene's
+// views and summing in registers: each output is written once, without atomics, and the
+// v-fold `repeat` backward of decoder_splatting_cuda.py:53-56 never materialises.
+//
+//   geometry  EWA covariance + projection backward -> dL/dmeans (part 1), dL/dcov,
+//             dL/dopacity, dL/dmeans2D, dL/dcolors.  Small register footprint.
+//   colour    SH backward, one wave per 64 Gaussians: coefficients staged in LDS with
+//             coalesced 16-byte loads, dL/dSH (75 accumulators per lane) leaves through the
+//             same slab with coalesced stores; adds the view-direction term to dL/dmeans.
 //
 // Semantics: SURVEY.md Appendix A.4 (upstream quirks kept: the 2-D mean gradient is in NDC
 // units, the frustum-guard clamp zeroes d/dt.x, d/dt.y, the off-diagonal conic gradient is
@@ -13,24 +19,18 @@
 
 namespace ps {
 
-template <int DEG>
 __global__ void __launch_bounds__(256)
-preprocess_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
-                           const float* __restrict__ cov, const float* __restrict__ sh,
-                           const float* __restrict__ view_params,
-                           const float* __restrict__ records, const int32_t* __restrict__ radii,
-                           const float* __restrict__ grad2d, float* __restrict__ dL_dmeans,
-                           float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
-                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-                           float* __restrict__ dL_dmeans2D) {
-  constexpr int NB = (DEG + 1) * (DEG + 1);
+geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
+                         const float* __restrict__ cov, const float* __restrict__ view_params,
+                         const int32_t* __restrict__ radii, const float* __restrict__ grad2d,
+                         float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov,
+                         float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                         float* __restrict__ dL_dmeans2D) {
   const int G = d.n_gaussians, vps = d.views_per_scene, H = d.height, W = d.width;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (g >= G) return;
   const size_t sg = (size_t)s * G + g;
-  const int K = d.sh_coeffs;
-  const bool use_sh = sh != nullptr;
 
   float m0[3], c6[6];
   {
@@ -45,27 +45,24 @@ preprocess_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
       c6[0] = cp[0]; c6[1] = cp[1]; c6[2] = cp[2]; c6[3] = cp[4]; c6[4] = cp[5]; c6[5] = cp[8];
     }
   }
-  float shc[NB * 3], dsh[NB * 3];
-  bool sh_loaded = false;
-#pragma unroll
-  for (int i = 0; i < NB * 3; ++i) dsh[i] = 0.f;
   float gm[3] = {0.f, 0.f, 0.f}, gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f;
 
   for (int j = 0; j < vps; ++j) {
     const int v = s * vps + j;
     const size_t vg = (size_t)v * G + g;
     const bool vis = radii[vg] > 0;
+    const float* gr = grad2d + vg * kGradFloats;
     if (dL_dmeans2D) {
       float* o = dL_dmeans2D + vg * 3;
-      o[0] = vis ? grad2d[vg * kGradFloats + 0] : 0.f;
-      o[1] = vis ? grad2d[vg * kGradFloats + 1] : 0.f;
+      o[0] = vis ? gr[0] : 0.f;
+      o[1] = vis ? gr[1] : 0.f;
       o[2] = 0.f;
     }
-    if (!use_sh && dL_dcolors) {
+    if (dL_dcolors) {
       float* o = dL_dcolors + vg * 3;
-      o[0] = vis ? grad2d[vg * kGradFloats + 6] : 0.f;
-      o[1] = vis ? grad2d[vg * kGradFloats + 7] : 0.f;
-      o[2] = vis ? grad2d[vg * kGradFloats + 8] : 0.f;
+      o[0] = vis ? gr[6] : 0.f;
+      o[1] = vis ? gr[7] : 0.f;
+      o[2] = vis ? gr[8] : 0.f;
     }
     if (!vis) continue;
     const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
@@ -73,10 +70,8 @@ preprocess_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
     const float* PV = vp + PS_VIEW_PROJMATRIX;
     const float tanfovx = vp[PS_VIEW_TANFOVX], tanfovy = vp[PS_VIEW_TANFOVY];
     const float scale = vp[PS_VIEW_SCALE], scale2 = scale * scale;
-    const float* gr = grad2d + vg * kGradFloats;
     const float gx2 = gr[0], gy2 = gr[1], gcx = gr[2], gcy = gr[3], gcz = gr[4];
-    const float g_op = gr[5], gr0 = gr[6], gr1 = gr[7], gr2 = gr[8];
-    const uint32_t clamp_bits = __float_as_uint(records[vg * kRecFloats + 11]);
+    const float g_op = gr[5];
 
     const float mx = m0[0] * scale, my = m0[1] * scale, mz = m0[2] * scale;
     const float tvx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
@@ -151,46 +146,6 @@ preprocess_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
       gmy += (PV[4] * m_w - PV[7] * mul1) * gx2 + (PV[5] * m_w - PV[7] * mul2) * gy2;
       gmz += (PV[8] * m_w - PV[11] * mul1) * gx2 + (PV[9] * m_w - PV[11] * mul2) * gy2;
     }
-    if (use_sh) {
-      if (!sh_loaded) {
-        const float* sp = sh + sg * (size_t)K * 3;
-        if (d.sh_layout == PS_SH_GK3) {
-#pragma unroll
-          for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) shc[k * 3 + ch] = sp[k * 3 + ch];
-        } else {
-#pragma unroll
-          for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) shc[k * 3 + ch] = sp[ch * K + k];
-        }
-        sh_loaded = true;
-      }
-      const float* cam = vp + PS_VIEW_CAMPOS;
-      const float ox = mx - cam[0], oy = my - cam[1], oz = mz - cam[2];
-      const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
-      const float x = ox * inv, y = oy * inv, z = oz * inv;
-      float bas[25], bx[25], by[25], bz[25];
-      sh_basis(DEG, x, y, z, bas);
-      sh_basis_grad(DEG, x, y, z, bx, by, bz);
-      const float gch[3] = {(clamp_bits & 1u) ? 0.f : gr0, (clamp_bits & 2u) ? 0.f : gr1,
-                            (clamp_bits & 4u) ? 0.f : gr2};
-      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float sv = shc[k * 3 + ch] * gch[ch];
-          dsh[k * 3 + ch] += bas[k] * gch[ch];
-          ddx += bx[k] * sv; ddy += by[k] * sv; ddz += bz[k] * sv;
-        }
-      }
-      const float dot = x * ddx + y * ddy + z * ddz;
-      gmx += (ddx - x * dot) * inv;
-      gmy += (ddy - y * dot) * inv;
-      gmz += (ddz - z * dot) * inv;
-    }
     gm[0] += scale * gmx; gm[1] += scale * gmy; gm[2] += scale * gmz;
     gop += g_op;
   }
@@ -207,9 +162,122 @@ preprocess_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
     oc[6] = 0.f; oc[7] = 0.f; oc[8] = gc[5];
   }
   dL_dopacity[sg] = gop;
-  if (use_sh && dL_dsh) {
-    float* os = dL_dsh + sg * (size_t)K * 3;
-    const bool gk3 = d.sh_layout == PS_SH_GK3;
+}
+
+// SH backward (runs after geometry_backward_kernel: it ADDS its dL/dmeans term).
+template <int DEG, bool LDS_SH>
+__global__ void __launch_bounds__(kWave)
+color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
+                      const float* __restrict__ sh, const float* __restrict__ view_params,
+                      const float* __restrict__ records, const int32_t* __restrict__ radii,
+                      const float* __restrict__ grad2d, float* __restrict__ dL_dmeans,
+                      float* __restrict__ dL_dsh) {
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  const int G = d.n_gaussians, vps = d.views_per_scene, K = d.sh_coeffs;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x * kWave + lane;
+  const int s = blockIdx.y;
+  const bool active = g < G;
+  const size_t sg = (size_t)s * G + (active ? g : 0);
+  const int S3 = K * 3;
+  const bool gk3 = d.sh_layout == PS_SH_GK3;
+
+  __shared__ float slab[LDS_SH ? kWave * 75 : 1];
+  const size_t g0 = (size_t)s * G + (size_t)blockIdx.x * kWave;
+  const int rem = G - (int)(blockIdx.x * kWave);
+  const int nflt = (rem < kWave ? rem : kWave) * S3;
+  float* my_slab = slab + (LDS_SH ? lane * S3 : 0);
+  const float* my_sh;
+  if (LDS_SH) {
+    const float* src = sh + g0 * (size_t)S3;
+    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
+      const float4* src4 = reinterpret_cast<const float4*>(src);
+      for (int i = lane; i * 4 < nflt; i += kWave) {
+        if (i * 4 + 3 < nflt) {
+          const float4 x = src4[i];
+          slab[i * 4] = x.x; slab[i * 4 + 1] = x.y; slab[i * 4 + 2] = x.z; slab[i * 4 + 3] = x.w;
+        } else {
+          for (int e = i * 4; e < nflt; ++e) slab[e] = src[e];
+        }
+      }
+    } else {
+      for (int i = lane; i < nflt; i += kWave) slab[i] = src[i];
+    }
+    __syncthreads();
+    my_sh = my_slab;
+  } else {
+    my_sh = sh + sg * (size_t)S3;
+  }
+
+  const float* mp = means + sg * 3;
+  const float m0x = mp[0], m0y = mp[1], m0z = mp[2];
+  float dsh[NB * 3];
+#pragma unroll
+  for (int i = 0; i < NB * 3; ++i) dsh[i] = 0.f;
+  float gmx = 0.f, gmy = 0.f, gmz = 0.f;
+
+  for (int j = 0; j < vps; ++j) {
+    const int v = s * vps + j;
+    const size_t vg = (size_t)v * G + (active ? g : 0);
+    if (!(active && radii[vg] > 0)) continue;
+    const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
+    const float scale = vp[PS_VIEW_SCALE];
+    const float* cam = vp + PS_VIEW_CAMPOS;
+    const float* gr = grad2d + vg * kGradFloats;
+    const uint32_t clamp_bits = __float_as_uint(records[vg * kRecFloats + 11]);
+    const float gch[3] = {(clamp_bits & 1u) ? 0.f : gr[6], (clamp_bits & 2u) ? 0.f : gr[7],
+                          (clamp_bits & 4u) ? 0.f : gr[8]};
+    const float ox = m0x * scale - cam[0], oy = m0y * scale - cam[1], oz = m0z * scale - cam[2];
+    const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox * inv, y = oy * inv, z = oz * inv;
+    float bas[25], w[25];
+    sh_basis(DEG, x, y, z, bas);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      float wk = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        dsh[k * 3 + ch] = fmaf(bas[k], gch[ch], dsh[k * 3 + ch]);
+        wk = fmaf(my_sh[gk3 ? k * 3 + ch : ch * K + k], gch[ch], wk);
+      }
+      w[k] = wk;
+    }
+    float ddx, ddy, ddz;
+    sh_grad_dot(DEG, x, y, z, w, ddx, ddy, ddz);
+    const float dot = x * ddx + y * ddy + z * ddz;
+    gmx += scale * ((ddx - x * dot) * inv);
+    gmy += scale * ((ddy - y * dot) * inv);
+    gmz += scale * ((ddz - z * dot) * inv);
+  }
+  if (active) {
+    float* om = dL_dmeans + sg * 3;
+    om[0] += gmx; om[1] += gmy; om[2] += gmz;
+  }
+  if (LDS_SH) {
+    // dL/dSH leaves through the slab: every lane drops its 3K values, then the wave streams
+    // the 64 x 3K block out with coalesced 16-byte stores
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) my_slab[gk3 ? k * 3 + ch : ch * K + k] = dsh[k * 3 + ch];
+    for (int k = NB; k < K; ++k)
+      for (int ch = 0; ch < 3; ++ch) my_slab[gk3 ? k * 3 + ch : ch * K + k] = 0.f;
+    __syncthreads();
+    float* dst = dL_dsh + g0 * (size_t)S3;
+    if ((reinterpret_cast<size_t>(dst) & 15) == 0) {
+      float4* dst4 = reinterpret_cast<float4*>(dst);
+      for (int i = lane; i * 4 < nflt; i += kWave) {
+        if (i * 4 + 3 < nflt)
+          dst4[i] = make_float4(slab[i * 4], slab[i * 4 + 1], slab[i * 4 + 2], slab[i * 4 + 3]);
+        else
+          for (int e = i * 4; e < nflt; ++e) dst[e] = slab[e];
+      }
+    } else {
+      for (int i = lane; i < nflt; i += kWave) dst[i] = slab[i];
+    }
+  } else if (active) {
+    float* os = dL_dsh + sg * (size_t)S3;
 #pragma unroll
     for (int k = 0; k < NB; ++k)
 #pragma unroll
@@ -224,12 +292,25 @@ void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const
                                 const int32_t* radii, const float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st) {
-  dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
+  {
+    dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
+    hipLaunchKernelGGL(geometry_backward_kernel, grid, block, 0, st, d, means, cov, view_params,
+                       radii, grad2d, dL_dmeans, dL_dcov, sh ? (float*)nullptr : dL_dcolors,
+                       dL_dopacity, dL_dmeans2D);
+  }
+  if (!sh) return;
+  const int deg = d.sh_degree;
+  const bool lds = ((d.sh_coeffs * 3) & 1) && d.sh_coeffs * 3 <= 75;
+  dim3 grid((d.n_gaussians + kWave - 1) / kWave, d.n_scenes), block(kWave);
 #define PS_LAUNCH(DEG)                                                                         \
-  hipLaunchKernelGGL(preprocess_backward_kernel<DEG>, grid, block, 0, st, d, means, cov, sh,   \
-                     view_params, records, radii, grad2d, dL_dmeans, dL_dcov, dL_dsh,          \
-                     dL_dcolors, dL_dopacity, dL_dmeans2D)
-  const int deg = sh ? d.sh_degree : 0;
+  do {                                                                                         \
+    if (lds)                                                                                   \
+      hipLaunchKernelGGL((color_backward_kernel<DEG, true>), grid, block, 0, st, d, means, sh, \
+                         view_params, records, radii, grad2d, dL_dmeans, dL_dsh);              \
+    else                                                                                       \
+      hipLaunchKernelGGL((color_backward_kernel<DEG, false>), grid, block, 0, st, d, means,    \
+                         sh, view_params, records, radii, grad2d, dL_dmeans, dL_dsh);          \
+  } while (0)
   switch (deg) {
     case 0: PS_LAUNCH(0); break;
     case 1: PS_LAUNCH(1); break;

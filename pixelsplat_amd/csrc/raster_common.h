@@ -82,12 +82,11 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii,
-                               uint32_t* n_vis, hipStream_t st);
+                               uint2* rects, int32_t* radii, hipStream_t st);
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                  uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
-                 const uint2* rects, uint2* sorted_rect, const uint32_t* n_vis, hipStream_t st);
+                 const uint2* rects, uint2* sorted_rect, uint32_t* n_vis, hipStream_t st);
 
 void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,
                       uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,

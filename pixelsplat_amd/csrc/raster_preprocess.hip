@@ -1,13 +1,24 @@
-// Per-Gaussian preprocess (forward): frustum cull, projection, EWA 2-D covariance, conic,
-// 3-sigma radius, tile rect, SH colour; one thread per scene Gaussian looping over the
-// scene's views so {mean, cov, SH, opacity} are read from HBM once per scene, not once per
-// view (the reference materialises v copies: decoder_splatting_cuda.py:53-56).
+// Per-Gaussian preprocess (forward), two kernels:
+//
+//   geometry  one thread per scene Gaussian, looping over the scene's views: frustum cull,
+//             projection, EWA 2-D covariance, conic, 3-sigma radius, tile rect, depth key.
+//             {mean, cov, opacity} are read once per scene, not once per view (the reference
+//             materialises v copies: decoder_splatting_cuda.py:53-56).  Small register
+//             footprint -> full occupancy; HBM-bound.
+//   colour    one wave per 64 Gaussians: the wave stages their SH coefficients (64 x 3K
+//             contiguous floats) in LDS with coalesced 16-byte loads -- 300 of the 340 input
+//             bytes per Gaussian -- then evaluates the degree<=4 colour for every view in
+//             which the Gaussian survived the cull.  Lane stride 3K is odd => conflict-free.
 //
 // Semantics: SURVEY.md Appendix A.1 -- what `GaussianRasterizer.forward` computes per
 // Gaussian for the call at /root/reference/src/model/decoder/cuda_splatting.py:117-124.
 //
 // THIS TRANSLATION UNIT IS BUILT WITH -ffp-contract=off: radius, tile rect and the depth
 // sort key are integer-valued functions of this arithmetic and must be bit-exact.
+//
+// Record (12 floats per (view, Gaussian), written only when visible):
+//   [0..3] px, py, conic.x, conic.y   [4..7] conic.z, opacity, depth, radius (int bits)
+//   [8..11] r, g, b, clamp bits
 #include "raster_common.h"
 #include "sh_math.h"
 
@@ -22,21 +33,18 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
-template <int DEG>
 __global__ void __launch_bounds__(256)
-preprocess_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
-                          const float* __restrict__ cov, const float* __restrict__ sh,
-                          const float* __restrict__ colors, const float* __restrict__ opacity,
-                          const float* __restrict__ view_params, float* __restrict__ records,
-                          uint32_t* __restrict__ keys, uint2* __restrict__ rects,
-                          int32_t* __restrict__ radii, uint32_t* __restrict__ n_vis) {
-  constexpr int NB = (DEG + 1) * (DEG + 1);
+geometry_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
+                        const float* __restrict__ cov, const float* __restrict__ colors,
+                        const float* __restrict__ opacity, const float* __restrict__ view_params,
+                        float* __restrict__ records, uint32_t* __restrict__ keys,
+                        uint2* __restrict__ rects, int32_t* __restrict__ radii) {
   const int G = d.n_gaussians, vps = d.views_per_scene, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
-  const bool active = g < G;
-  const size_t sg = (size_t)s * G + (active ? g : 0);
+  if (g >= G) return;
+  const size_t sg = (size_t)s * G + g;
 
   float m0[3], c6[6], opac;
   {
@@ -52,8 +60,6 @@ preprocess_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
     }
     opac = opacity[sg];
   }
-  float shc[NB * 3];
-  bool sh_loaded = false;
 
   for (int j = 0; j < vps; ++j) {
     const int v = s * vps + j;
@@ -63,13 +69,13 @@ preprocess_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
     const float tanfovx = vp[PS_VIEW_TANFOVX], tanfovy = vp[PS_VIEW_TANFOVY];
     const float scale = vp[PS_VIEW_SCALE];
     const float scale2 = scale * scale;
-    const size_t vg = (size_t)v * G + (active ? g : 0);
+    const size_t vg = (size_t)v * G + g;
 
     const float mx = m0[0] * scale, my = m0[1] * scale, mz = m0[2] * scale;
     const float tvx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
     const float tvy = V[1] * mx + V[5] * my + V[9] * mz + V[13];
     const float tvz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
-    bool vis = active && (tvz > d.near_cull);
+    bool vis = tvz > d.near_cull;
 
     int radius = 0, xmin = 0, ymin = 0, xmax = 0, ymax = 0;
     float px = 0.f, py = 0.f, con_x = 0.f, con_y = 0.f, con_z = 0.f;
@@ -123,73 +129,127 @@ preprocess_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
       }
     }
 
-    float rgb[3] = {0.f, 0.f, 0.f};
-    uint32_t clamp_bits = 0;
+    radii[vg] = vis ? radius : 0;
+    keys[vg] = vis ? __float_as_uint(tvz) : kCulledKey;
     if (vis) {
-      if (sh != nullptr) {
-        if (!sh_loaded) {
-          const int K = d.sh_coeffs;
-          const float* sp = sh + sg * (size_t)K * 3;
-          if (d.sh_layout == PS_SH_GK3) {
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-#pragma unroll
-              for (int c = 0; c < 3; ++c) shc[k * 3 + c] = sp[k * 3 + c];
-          } else {
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-#pragma unroll
-              for (int c = 0; c < 3; ++c) shc[k * 3 + c] = sp[c * K + k];
-          }
-          sh_loaded = true;
-        }
-        const float* cam = vp + PS_VIEW_CAMPOS;
-        float dx = mx - cam[0], dy = my - cam[1], dz = mz - cam[2];
-        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        dx = dx / len; dy = dy / len; dz = dz / len;
-        float b[25];
-        sh_basis(DEG, dx, dy, dz, b);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float acc = 0.f;
-#pragma unroll
-          for (int k = 0; k < NB; ++k) acc = acc + b[k] * shc[k * 3 + c];
-          acc = acc + 0.5f;
-          if (acc < 0.f) clamp_bits |= (1u << c);
-          rgb[c] = fmaxf(acc, 0.f);
-        }
-      } else {
+      rects[vg] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16),
+                             (uint32_t)xmax | ((uint32_t)ymax << 16));
+      float4* r = reinterpret_cast<float4*>(records + vg * kRecFloats);
+      r[0] = make_float4(px, py, con_x, con_y);
+      r[1] = make_float4(con_z, opac, tvz, __int_as_float(radius));
+      if (colors != nullptr) {   // colors_precomp: verbatim, no clamp
         const float* cp = colors + vg * 3;
-        rgb[0] = cp[0]; rgb[1] = cp[1]; rgb[2] = cp[2];
+        r[2] = make_float4(cp[0], cp[1], cp[2], __uint_as_float(0u));
       }
     }
+  }
+}
 
-    if (active) {
-      radii[vg] = vis ? radius : 0;
-      keys[vg] = vis ? __float_as_uint(tvz) : kCulledKey;
-      if (vis) {
-        rects[vg] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16),
-                               (uint32_t)xmax | ((uint32_t)ymax << 16));
-        float4* r = reinterpret_cast<float4*>(records + vg * kRecFloats);
-        r[0] = make_float4(px, py, con_x, con_y);
-        r[1] = make_float4(con_z, opac, rgb[0], rgb[1]);
-        r[2] = make_float4(rgb[2], tvz, __int_as_float(radius), __uint_as_float(clamp_bits));
+// SH -> RGB for the (view, Gaussian) pairs that survived the cull.
+// LDS_SH: slab staged through LDS (3K odd and <= 75); otherwise direct per-lane loads.
+template <int DEG, bool LDS_SH>
+__global__ void __launch_bounds__(kWave)
+color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
+                     const float* __restrict__ sh, const float* __restrict__ view_params,
+                     const int32_t* __restrict__ radii, float* __restrict__ records) {
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  const int G = d.n_gaussians, vps = d.views_per_scene, K = d.sh_coeffs;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x * kWave + lane;
+  const int s = blockIdx.y;
+  const bool active = g < G;
+  const size_t sg = (size_t)s * G + (active ? g : 0);
+  const int S3 = K * 3;
+
+  // which views need a colour at all?  (skip the slab load if nobody in the wave does)
+  uint32_t vis_bits = 0;
+  for (int j = 0; j < vps && j < 32; ++j)
+    if (active && radii[(size_t)(s * vps + j) * G + g] > 0) vis_bits |= 1u << j;
+  if (vps > 32) vis_bits = active ? 0xFFFFFFFFu : 0u;
+  if (__ballot(vis_bits != 0u) == 0ull) return;
+
+  __shared__ float slab[LDS_SH ? kWave * 75 : 1];
+  const float* my_sh;
+  if (LDS_SH) {
+    const size_t g0 = (size_t)s * G + (size_t)blockIdx.x * kWave;
+    const int rem = G - (int)(blockIdx.x * kWave);
+    const int nflt = (rem < kWave ? rem : kWave) * S3;
+    const float* src = sh + g0 * (size_t)S3;
+    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
+      const float4* src4 = reinterpret_cast<const float4*>(src);
+      for (int i = lane; i * 4 < nflt; i += kWave) {
+        if (i * 4 + 3 < nflt) {
+          const float4 x = src4[i];
+          slab[i * 4] = x.x; slab[i * 4 + 1] = x.y; slab[i * 4 + 2] = x.z; slab[i * 4 + 3] = x.w;
+        } else {
+          for (int e = i * 4; e < nflt; ++e) slab[e] = src[e];
+        }
       }
+    } else {
+      for (int i = lane; i < nflt; i += kWave) slab[i] = src[i];
     }
-    const uint64_t m = __ballot(vis);
-    if (m != 0ull && lane_id() == 0) atomicAdd(&n_vis[v], (uint32_t)__popcll(m));
+    __syncthreads();
+    my_sh = slab + lane * S3;
+  } else {
+    my_sh = sh + sg * (size_t)S3;
+  }
+  const bool gk3 = d.sh_layout == PS_SH_GK3;
+  const float* mp = means + sg * 3;
+  const float m0x = mp[0], m0y = mp[1], m0z = mp[2];
+
+  for (int j = 0; j < vps; ++j) {
+    const bool vis = j < 32 ? ((vis_bits >> j) & 1u) != 0u
+                            : (active && radii[(size_t)(s * vps + j) * G + g] > 0);
+    if (!vis) continue;
+    const int v = s * vps + j;
+    const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
+    const float scale = vp[PS_VIEW_SCALE];
+    const float* cam = vp + PS_VIEW_CAMPOS;
+    const float mx = m0x * scale, my = m0y * scale, mz = m0z * scale;
+    float dx = mx - cam[0], dy = my - cam[1], dz = mz - cam[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    float b[25];
+    sh_basis(DEG, dx, dy, dz, b);
+    float rgb[3];
+    uint32_t clamp_bits = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) acc = acc + b[k] * my_sh[gk3 ? k * 3 + c : c * K + k];
+      acc = acc + 0.5f;
+      if (acc < 0.f) clamp_bits |= (1u << c);
+      rgb[c] = fmaxf(acc, 0.f);
+    }
+    float4* r = reinterpret_cast<float4*>(records + ((size_t)v * G + g) * kRecFloats);
+    r[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
   }
 }
 
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, uint32_t* n_vis, hipStream_t st) {
-  dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
-#define PS_LAUNCH(DEG)                                                                       \
-  hipLaunchKernelGGL(preprocess_forward_kernel<DEG>, grid, block, 0, st, d, means, cov, sh,  \
-                     colors, opacity, view_params, records, keys, rects, radii, n_vis)
-  const int deg = sh ? d.sh_degree : 0;
+                               uint2* rects, int32_t* radii, hipStream_t st) {
+  {
+    dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
+    hipLaunchKernelGGL(geometry_forward_kernel, grid, block, 0, st, d, means, cov, colors,
+                       opacity, view_params, records, keys, rects, radii);
+  }
+  if (!sh) return;
+  const int deg = d.sh_degree;
+  // LDS staging needs an odd float stride per Gaussian (K = 1, 9, 25), at most 75
+  const bool lds = ((d.sh_coeffs * 3) & 1) && d.sh_coeffs * 3 <= 75;
+  dim3 grid((d.n_gaussians + kWave - 1) / kWave, d.n_scenes), block(kWave);
+#define PS_LAUNCH(DEG)                                                                        \
+  do {                                                                                        \
+    if (lds)                                                                                  \
+      hipLaunchKernelGGL((color_forward_kernel<DEG, true>), grid, block, 0, st, d, means, sh, \
+                         view_params, radii, records);                                        \
+    else                                                                                      \
+      hipLaunchKernelGGL((color_forward_kernel<DEG, false>), grid, block, 0, st, d, means,    \
+                         sh, view_params, radii, records);                                    \
+  } while (0)
   switch (deg) {
     case 0: PS_LAUNCH(0); break;
     case 1: PS_LAUNCH(1); break;

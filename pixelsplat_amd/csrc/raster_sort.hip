@@ -32,7 +32,7 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
 
 // one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order
 __global__ void __launch_bounds__(256)
-sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk) {
+sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restrict__ n_vis) {
   __shared__ uint32_t tot[256];
   const int v = blockIdx.x, dgt = threadIdx.x;
   uint32_t* row = block_hist + ((size_t)v * 256 + dgt) * nblk;
@@ -50,6 +50,9 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk) {
   }
   const uint32_t excl = x - sum;
   for (int b = 0; b < nblk; ++b) row[b] += excl;
+  // last pass only: keys below the top digit 0xFF are exactly the visible ones (depth > 0
+  // has top byte <= 0x7F; culled entries carry 0xFFFFFFFF) -> n_vis without any atomics
+  if (n_vis != nullptr && dgt == 255) n_vis[v] = excl;
 }
 
 template <bool IOTA_VALS>
@@ -125,7 +128,7 @@ gather_rects_kernel(const uint32_t* __restrict__ sorted_idx, const uint2* __rest
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                  uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
-                 const uint2* rects, uint2* sorted_rect, const uint32_t* n_vis, hipStream_t st) {
+                 const uint2* rects, uint2* sorted_rect, uint32_t* n_vis, hipStream_t st) {
   const Dims m = make_dims(d);
   dim3 grid(m.nblk, m.V), block(kSortThreads);
   uint32_t* kin = keys_a; uint32_t* kout = keys_b;
@@ -133,7 +136,8 @@ void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = pass * 8;
     hipLaunchKernelGGL(sort_hist_kernel, grid, block, 0, st, kin, block_hist, m.G, m.nblk, shift);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(256), 0, st, block_hist, m.nblk);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(256), 0, st, block_hist, m.nblk,
+                       pass == 3 ? n_vis : (uint32_t*)nullptr);
     if (pass == 0)
       hipLaunchKernelGGL(sort_scatter_kernel<true>, grid, block, 0, st, kin, vin, kout, vout,
                          block_hist, m.G, m.nblk, shift);

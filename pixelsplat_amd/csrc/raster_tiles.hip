@@ -161,14 +161,13 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     if ((uint32_t)lane < m) {
       const uint32_t id = list[first + lane];
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
-      const float4 r0 = r[0], r1 = r[1];
-      const float bch = recs[(size_t)id * kRecFloats + 8];
+      const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
       const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
       keep = qm != 0u;
       q0 = make_float4(r0.x, r0.y, A, B);
-      q1 = make_float4(Cq, r1.y, r1.z, r1.w);
-      q2 = make_float4(bch, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
+      q1 = make_float4(Cq, r1.y, r2.x, r2.y);
+      q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
     }
     const uint64_t mask = __ballot(keep);
     if (keep) {
@@ -334,14 +333,13 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     if ((uint32_t)lane < m) {
       const uint32_t id = list[top - 1u - lane];
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
-      const float4 r0 = r[0], r1 = r[1];
-      const float bch = recs[(size_t)id * kRecFloats + 8];
+      const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
       const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
       keep = qm != 0u;
       q0 = make_float4(r0.x, r0.y, A, B);
-      q1 = make_float4(Cq, r1.y, r1.z, r1.w);
-      q2 = make_float4(bch, __uint_as_float(top - lane), __uint_as_float(qm),
+      q1 = make_float4(Cq, r1.y, r2.x, r2.y);
+      q2 = make_float4(r2.z, __uint_as_float(top - lane), __uint_as_float(qm),
                        __uint_as_float(id));
     }
     const uint64_t mask = __ballot(keep);

@@ -109,3 +109,52 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 }
 
 }  // namespace ps
+
+namespace ps {
+
+// (ddx, ddy, ddz) = sum_k w[k] * d basis_k / d(x, y, z) without materialising the 75
+// partial derivatives (keeps the SH backward kernel's live registers low).
+__device__ __forceinline__ void sh_grad_dot(int deg, float x, float y, float z, const float* w,
+                                            float& ddx, float& ddy, float& ddz) {
+  ddx = 0.f; ddy = 0.f; ddz = 0.f;
+#define PS_ACC(k, gx_, gy_, gz_) \
+  do { ddx = fmaf((gx_), w[k], ddx); ddy = fmaf((gy_), w[k], ddy); ddz = fmaf((gz_), w[k], ddz); } while (0)
+  if (deg < 1) return;
+  PS_ACC(1, 0.f, -PS_C1, 0.f);
+  PS_ACC(2, 0.f, 0.f, PS_C1);
+  PS_ACC(3, -PS_C1, 0.f, 0.f);
+  if (deg < 2) return;
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+  PS_ACC(4, PS_C2_0 * y, PS_C2_0 * x, 0.f);
+  PS_ACC(5, 0.f, PS_C2_1 * z, PS_C2_1 * y);
+  PS_ACC(6, PS_C2_2 * (-2.0f * x), PS_C2_2 * (-2.0f * y), PS_C2_2 * (4.0f * z));
+  PS_ACC(7, PS_C2_3 * z, 0.f, PS_C2_3 * x);
+  PS_ACC(8, PS_C2_4 * (2.0f * x), PS_C2_4 * (-2.0f * y), 0.f);
+  if (deg < 3) return;
+  PS_ACC(9, PS_C3_0 * (6.0f * xy), PS_C3_0 * (3.0f * xx - 3.0f * yy), 0.f);
+  PS_ACC(10, PS_C3_1 * yz, PS_C3_1 * xz, PS_C3_1 * xy);
+  PS_ACC(11, PS_C3_2 * (-2.0f * xy), PS_C3_2 * (4.0f * zz - xx - 3.0f * yy), PS_C3_2 * (8.0f * yz));
+  PS_ACC(12, PS_C3_3 * (-6.0f * xz), PS_C3_3 * (-6.0f * yz),
+         PS_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+  PS_ACC(13, PS_C3_4 * (4.0f * zz - 3.0f * xx - yy), PS_C3_4 * (-2.0f * xy), PS_C3_4 * (8.0f * xz));
+  PS_ACC(14, PS_C3_5 * (2.0f * xz), PS_C3_5 * (-2.0f * yz), PS_C3_5 * (xx - yy));
+  PS_ACC(15, PS_C3_6 * (3.0f * xx - 3.0f * yy), PS_C3_6 * (-6.0f * xy), 0.f);
+  if (deg < 4) return;
+  PS_ACC(16, PS_C4_0 * (3.0f * xx * y - yy * y), PS_C4_0 * (xx * x - 3.0f * x * yy), 0.f);
+  PS_ACC(17, PS_C4_1 * (6.0f * xy * z), PS_C4_1 * (z * (3.0f * xx - 3.0f * yy)),
+         PS_C4_1 * (y * (3.0f * xx - yy)));
+  PS_ACC(18, PS_C4_2 * (y * (7.0f * zz - 1.0f)), PS_C4_2 * (x * (7.0f * zz - 1.0f)),
+         PS_C4_2 * (14.0f * xy * z));
+  PS_ACC(19, 0.f, PS_C4_3 * (z * (7.0f * zz - 3.0f)), PS_C4_3 * (y * (21.0f * zz - 3.0f)));
+  PS_ACC(20, 0.f, 0.f, PS_C4_4 * (140.0f * zz * z - 60.0f * z));
+  PS_ACC(21, PS_C4_5 * (z * (7.0f * zz - 3.0f)), 0.f, PS_C4_5 * (x * (21.0f * zz - 3.0f)));
+  PS_ACC(22, PS_C4_6 * (2.0f * x * (7.0f * zz - 1.0f)), PS_C4_6 * (-2.0f * y * (7.0f * zz - 1.0f)),
+         PS_C4_6 * (14.0f * z * (xx - yy)));
+  PS_ACC(23, PS_C4_7 * (z * (3.0f * xx - 3.0f * yy)), PS_C4_7 * (-6.0f * xy * z),
+         PS_C4_7 * (x * (xx - 3.0f * yy)));
+  PS_ACC(24, PS_C4_8 * (4.0f * xx * x - 12.0f * x * yy), PS_C4_8 * (4.0f * yy * y - 12.0f * xx * y),
+         0.f);
+#undef PS_ACC
+}
+
+}  // namespace ps

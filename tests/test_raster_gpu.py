@@ -166,7 +166,7 @@ def test_full_size_properties(gpu_device):
     sv = state_views(aux["cfg"], aux["state"], aux["layout"])
     counts, offsets, plist = export_bins(aux["cfg"], aux["state"], aux["layout"], aux["point_list"])
     rec = sv["records"]
-    depth = rec[..., 9]
+    depth = rec[..., 6]
     rects = sv["rects"].to(torch.int64)
     gx = 16
     plist = plist.to(torch.int64)
