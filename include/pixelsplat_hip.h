@@ -94,6 +94,7 @@ typedef struct PsRasterStateLayout {
   size_t tile_end;    /* uint32[V][T]: max n_contrib in the tile (where the backward walk starts) */
   size_t tile_ranges; /* uint32[V][T][2]: (start, count) of the tile's list in point_list     */
   size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
+  size_t tile_order;  /* uint32[V*T]: (view,tile) ids, longest list first (launch order)      */
   size_t total;
 } PsRasterStateLayout;
 

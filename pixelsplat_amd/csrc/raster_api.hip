@@ -74,7 +74,7 @@ namespace {
 struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
   float* final_T; uint32_t* n_contrib; uint32_t* tile_end; uint32_t* tile_ranges;
-  uint32_t* num_rendered;
+  uint32_t* num_rendered; uint32_t* tile_order;
   uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *bin_counts;
 };
 FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
@@ -88,6 +88,7 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.n_contrib = (uint32_t*)(sb + L.n_contrib); p.tile_end = (uint32_t*)(sb + L.tile_end);
   p.tile_ranges = (uint32_t*)(sb + L.tile_ranges);
   p.num_rendered = (uint32_t*)(sb + L.num_rendered);
+  p.tile_order = (uint32_t*)(sb + L.tile_order);
   p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
   p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
   p.block_hist = (uint32_t*)(tb + T.block_hist); p.bin_counts = (uint32_t*)(tb + T.bin_counts);
@@ -129,7 +130,8 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   }
   {
     Scope sc(G_BINS, st);
-    launch_bin_count(*d, p.sorted_rect, p.n_vis, p.bin_counts, p.tile_ranges, p.num_rendered, st);
+    launch_bin_count(*d, p.sorted_rect, p.n_vis, p.bin_counts, p.tile_ranges, p.num_rendered,
+                     p.tile_order, st);
   }
   return check_launch();
 }
@@ -150,7 +152,8 @@ int ps_raster_forward_render(const PsRasterDesc* d, const float* view_params, fl
   }
   {
     Scope sc(G_TILES_FWD, st);
-    launch_tiles_forward(*d, p.records, p.tile_ranges, point_list, cap, view_params, out_color,
+    launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list, cap, view_params,
+                         out_color,
                          p.final_T, p.n_contrib, p.tile_end, st);
   }
   return check_launch();
@@ -190,6 +193,7 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   const char* sb = (const char*)state; char* tb = (char*)temp;
   const float* records = (const float*)(sb + L.records);
   const uint32_t* tile_ranges = (const uint32_t*)(sb + L.tile_ranges);
+  const uint32_t* tile_order = (const uint32_t*)(sb + L.tile_order);
   const uint32_t capacity = clamp_capacity(list_capacity);
   if (!point_list && capacity > 0) return PS_ERR_BAD_ARG;
   const float* final_T = (const float*)(sb + L.final_T);
@@ -202,7 +206,8 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   }
   {
     Scope sc(G_TILES_BWD, st);
-    launch_tiles_backward(*d, records, tile_ranges, point_list, capacity, view_params, final_T,
+    launch_tiles_backward(*d, records, tile_order, tile_ranges, point_list, capacity, view_params,
+                          final_T,
                           n_contrib, tile_end, dL_dcolor, grad2d, st);
   }
   {

@@ -78,8 +78,11 @@ bin_scan_blocks_kernel(PsRasterDesc d, uint32_t* __restrict__ counts,
 // single block: exclusive scan of the V*tiles tile totals -> tile starts, D, overflow flag
 __global__ void __launch_bounds__(1024)
 bin_scan_tiles_kernel(PsRasterDesc d, uint32_t* __restrict__ tile_ranges,
-                      uint32_t* __restrict__ num_rendered /*[2]: D, overflow*/) {
+                      uint32_t* __restrict__ num_rendered /*[2]: D, overflow*/,
+                      uint32_t* __restrict__ tile_order) {
   __shared__ uint32_t part[1024];
+  __shared__ uint32_t hist[1024];
+  __shared__ uint32_t s_max;
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   const int per = (total + 1023) / 1024;
@@ -104,6 +107,37 @@ bin_scan_tiles_kernel(PsRasterDesc d, uint32_t* __restrict__ tile_ranges,
     num_rendered[0] = x;
     num_rendered[1] = 0u;
   }
+  // Longest-list-first launch order for the tile kernels (one wave per tile, dispatched in
+  // block order => LPT scheduling): counting sort of the tiles by list length, 1024 buckets.
+  if (threadIdx.x == 0) s_max = 1u;
+  hist[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (int i = lo; i < hi; ++i) { const uint32_t c = tile_ranges[2 * (size_t)i + 1]; mx = c > mx ? c : mx; }
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const uint32_t maxc = s_max;
+  auto bucket = [&](uint32_t c) -> uint32_t {   // 0 = longest
+    return 1023u - (uint32_t)(((uint64_t)c * 1023ull) / maxc);
+  };
+  for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(tile_ranges[2 * (size_t)i + 1])], 1u);
+  __syncthreads();
+  const uint32_t hsum = hist[threadIdx.x];
+  part[threadIdx.x] = hsum;
+  __syncthreads();
+  uint32_t hx = hsum;
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t y = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    hx += y; part[threadIdx.x] = hx;
+    __syncthreads();
+  }
+  hist[threadIdx.x] = hx - hsum;   // exclusive start of the bucket
+  __syncthreads();
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t pos = atomicAdd(&hist[bucket(tile_ranges[2 * (size_t)i + 1])], 1u);
+    tile_order[pos] = (uint32_t)i;
+  }
 }
 
 __global__ void bin_flag_kernel(uint32_t* __restrict__ num_rendered, uint32_t capacity) {
@@ -113,7 +147,7 @@ __global__ void bin_flag_kernel(uint32_t* __restrict__ num_rendered, uint32_t ca
 // count + scans: everything that does not need the point list (whose size, D, they produce)
 void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,
                       uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,
-                      hipStream_t st) {
+                      uint32_t* tile_order, hipStream_t st) {
   const Dims m = make_dims(d);
   (void)hipMemsetAsync(counts, 0, (size_t)m.V * m.nbin * m.tiles * 4, st);
   dim3 grid(m.nbin, m.V);
@@ -123,7 +157,7 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
   hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3((m.V * m.tiles + 255) / 256), dim3(256), 0, st,
                      d, counts, tile_ranges);
   hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, d, tile_ranges,
-                     num_rendered);
+                     num_rendered, tile_order);
 }
 
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,

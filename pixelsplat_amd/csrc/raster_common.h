@@ -74,6 +74,7 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.tile_end = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
   s.tile_ranges = o; o = align_up(o + (size_t)m.V * m.tiles * 8);
   s.num_rendered = o; o = align_up(o + 8);
+  s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
   s.total = o;
   return s;
 }
@@ -90,20 +91,22 @@ void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint
 
 void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,
                       uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,
-                      hipStream_t st);
+                      uint32_t* tile_order, hipStream_t st);
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
                       const uint32_t* n_vis, uint32_t* counts, const uint32_t* tile_ranges,
                       uint32_t* num_rendered, uint32_t* point_list, uint32_t capacity,
                       hipStream_t st);
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
-                          const uint32_t* tile_ranges, const uint32_t* point_list,
+                          const uint32_t* tile_order, const uint32_t* tile_ranges,
+                          const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
                           hipStream_t st);
 
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
-                           const uint32_t* tile_ranges, const uint32_t* point_list,
+                           const uint32_t* tile_order, const uint32_t* tile_ranges,
+                           const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const uint32_t* tile_end,
                            const float* dL_dcolor, float* grad2d, hipStream_t st);

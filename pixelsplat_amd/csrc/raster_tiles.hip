@@ -114,6 +114,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, f
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWavesPerBlock* kWave)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
+                     const uint32_t* __restrict__ tile_order,
                      const uint32_t* __restrict__ tile_ranges,
                      const uint32_t* __restrict__ point_list, uint32_t capacity,
                      const float* __restrict__ view_params, float* __restrict__ out_color,
@@ -125,8 +126,9 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int tiles = gx * gy;
   const int V = d.n_scenes * d.views_per_scene;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile_global = blockIdx.x * kWavesPerBlock + w;
-  if (tile_global >= V * tiles) return;
+  const int slot_global = blockIdx.x * kWavesPerBlock + w;
+  if (slot_global >= V * tiles) return;
+  const int tile_global = (int)tile_order[slot_global];   // longest lists are launched first
   WaveLds& lds = lds_all[w];
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
@@ -239,38 +241,54 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
 }
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
-                          const uint32_t* tile_ranges, const uint32_t* point_list,
+                          const uint32_t* tile_order, const uint32_t* tile_ranges,
+                          const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
                           hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_ranges,
+  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
                      point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
 }
 
 // ------------------------------------------------------------------------------------
 // backward: walk the tile's bin back to front from the last contributor
 // ------------------------------------------------------------------------------------
-// Wave64 sum by DPP (one fused shift+add per step); the total lands in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
-  return v + __int_as_float(moved);
+// Wave64 sums by DPP, nine values at a time: one fused shift+add (v_add_f32_dpp) per value
+// per step, six steps, totals land in lane 63.  The nine chains are interleaved so two DPP
+// ops on the same register are always >= 9 instructions apart (the VALU-write -> DPP-read
+// hazard needs 2 wait states and hipcc pads nothing inside an asm block).
+#define PS_DPP_STEP(ctrl)                                   \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                     \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                     \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                     \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                     \
+  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                     \
+  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                     \
+  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                     \
+  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                     \
+  "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
+__device__ __forceinline__ void wave_sum9_to_lane63(float& a, float& b, float& c, float& d,
+                                                    float& e, float& f, float& g, float& h,
+                                                    float& i) {
+  asm volatile(
+      "s_nop 1\n"
+      PS_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      PS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      PS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      PS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")   // lane 15 of a row = row total
+      PS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")              // rows 1,3 += row 0,2 totals
+      PS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")              // lane 63 = wave total
+      "s_nop 1\n"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xF>(v);  // row_shr:8  -> lane 15 of each row holds the row total
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
-  return v;
-}
+#undef PS_DPP_STEP
 
 __global__ void __launch_bounds__(kWavesPerBlock* kWave)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
+                      const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_ranges,
                       const uint32_t* __restrict__ point_list, uint32_t capacity,
                       const float* __restrict__ view_params, const float* __restrict__ final_T,
@@ -283,8 +301,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int tiles = gx * gy;
   const int V = d.n_scenes * d.views_per_scene;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile_global = blockIdx.x * kWavesPerBlock + w;
-  if (tile_global >= V * tiles) return;
+  const int slot_global = blockIdx.x * kWavesPerBlock + w;
+  if (slot_global >= V * tiles) return;
+  const int tile_global = (int)tile_order[slot_global];   // longest lists are launched first
   WaveLdsBwd& lds = lds_all[w];
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
@@ -394,19 +413,11 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       }
       if (__any(any)) {
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
-        Mx = wave_sum_to_lane63(Mx);
-        My = wave_sum_to_lane63(My);
-        Mxx = wave_sum_to_lane63(Mxx);
-        Mxy = wave_sum_to_lane63(Mxy);
-        Myy = wave_sum_to_lane63(Myy);
-        const float sop = wave_sum_to_lane63(s_op);
-        const float sr = wave_sum_to_lane63(s_r);
-        const float sg = wave_sum_to_lane63(s_g);
-        const float sb = wave_sum_to_lane63(s_b);
+        wave_sum9_to_lane63(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b);
         if (lane == 63) {
           float* gs = lds.gsum[j];
-          gs[0] = Mx; gs[1] = My; gs[2] = Mxx; gs[3] = Mxy; gs[4] = Myy; gs[5] = sop;
-          gs[6] = sr; gs[7] = sg; gs[8] = sb; gs[9] = 1.f;
+          gs[0] = Mx; gs[1] = My; gs[2] = Mxx; gs[3] = Mxy; gs[4] = Myy; gs[5] = s_op;
+          gs[6] = s_r; gs[7] = s_g; gs[8] = s_b; gs[9] = 1.f;
         }
       } else if (lane == 63) {
         lds.gsum[j][9] = 0.f;
@@ -446,14 +457,16 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
 }
 
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
-                           const uint32_t* tile_ranges, const uint32_t* point_list,
+                           const uint32_t* tile_order, const uint32_t* tile_ranges,
+                           const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const uint32_t* tile_end,
                            const float* dL_dcolor, float* grad2d, hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_ranges,
+  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order,
+                     tile_ranges,
                      point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
                      grad2d);
 }
