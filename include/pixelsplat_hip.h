@@ -84,7 +84,7 @@ typedef struct PsRasterDesc {
 /* byte offsets of the arrays inside the `state` buffer (for tests / debugging).
  * V = n_scenes*views_per_scene, N = V*G, P = H*W, T = tiles per view. */
 typedef struct PsRasterStateLayout {
-  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,depth,radius(i32) | r,g,b,clamp bits */
+  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,depth,tiles touched(i32) | r,g,b,clamp bits */
   size_t rects;       /* uint16[N][4]: tile rect xmin,ymin,xmax,ymax                   */
   size_t sorted_idx;  /* uint32[N]: per view, Gaussian ids in (depth, id) order; first n_vis valid */
   size_t sorted_rect; /* uint16[N][4]: rects permuted into sorted order                */
@@ -95,12 +95,14 @@ typedef struct PsRasterStateLayout {
   size_t tile_ranges; /* uint32[V][T][2]: (start, count) of the tile's list in point_list     */
   size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
   size_t tile_order;  /* uint32[V*T]: (view,tile) ids, longest list first (launch order)      */
+  size_t inv_slots;   /* uint32[N][4]: point-list positions of a Gaussian touching <= 4 tiles  */
   size_t total;
 } PsRasterStateLayout;
 
 void ps_raster_default_desc(PsRasterDesc* desc);
 size_t ps_raster_state_bytes(const PsRasterDesc* desc); /* lives from forward to backward */
-size_t ps_raster_temp_bytes(const PsRasterDesc* desc);  /* scratch of one call            */
+size_t ps_raster_temp_bytes(const PsRasterDesc* desc);  /* scratch of one forward call    */
+size_t ps_raster_backward_temp_bytes(const PsRasterDesc* desc, size_t list_capacity);
 int ps_raster_state_layout(const PsRasterDesc* desc, PsRasterStateLayout* out);
 
 /* Forward.  Replaces GaussianRasterizer.forward (cuda_splatting.py:117-124).
@@ -146,6 +148,9 @@ int ps_raster_forward_render(const PsRasterDesc* desc, const float* view_params,
  *   dL_dsh      as sh layout, or NULL    dL_dcolors float[V][G][3], or NULL
  *   dL_dopacity float[S][G]
  *   dL_dmeans2D float[V][G][3] (NDC-scaled screen-space gradient, z = 0), may be NULL
+ * temp_bytes >= ps_raster_backward_temp_bytes(desc, list_capacity).  The per-(tile, Gaussian)
+ * partial gradients of Gaussians that touch <= 4 tiles are written to private slots and
+ * summed in a fixed order (deterministic, no float atomics); larger ones use atomics.
  * Gradients are summed over the views of a scene (what autograd's `repeat` backward does,
  * decoder_splatting_cuda.py:53-56) and include the scene_scale chain rule.
  */

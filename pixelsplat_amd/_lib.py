@@ -33,12 +33,13 @@ class PsRasterDesc(C.Structure):
 class PsRasterStateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "records", "rects", "sorted_idx", "sorted_rect", "n_vis", "final_T", "n_contrib",
-        "tile_end", "tile_ranges", "num_rendered", "tile_order", "total")]
+        "tile_end", "tile_ranges", "num_rendered", "tile_order", "inv_slots", "total")]
 
 
 # every symbol include/pixelsplat_hip.h declares
 EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
+    "ps_raster_backward_temp_bytes",
     "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
     "ps_raster_forward_render", "ps_raster_backward",
     "ps_raster_check", "ps_status_string", "ps_build_info",
@@ -72,6 +73,8 @@ def load():
     lib.ps_raster_state_bytes.restype = C.c_size_t
     lib.ps_raster_temp_bytes.argtypes = [C.POINTER(PsRasterDesc)]
     lib.ps_raster_temp_bytes.restype = C.c_size_t
+    lib.ps_raster_backward_temp_bytes.argtypes = [C.POINTER(PsRasterDesc), C.c_size_t]
+    lib.ps_raster_backward_temp_bytes.restype = C.c_size_t
     lib.ps_raster_state_layout.argtypes = [C.POINTER(PsRasterDesc), C.POINTER(PsRasterStateLayout)]
     lib.ps_raster_state_layout.restype = C.c_int
     lib.ps_raster_forward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [

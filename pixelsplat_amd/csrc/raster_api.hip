@@ -64,6 +64,9 @@ size_t ps_raster_state_bytes(const PsRasterDesc* d) {
 size_t ps_raster_temp_bytes(const PsRasterDesc* d) {
   return desc_ok(d) ? make_temp_layout(*d).total : 0;
 }
+size_t ps_raster_backward_temp_bytes(const PsRasterDesc* d, size_t list_capacity) {
+  return desc_ok(d) ? make_bwd_temp_layout(*d, list_capacity).total : 0;
+}
 int ps_raster_state_layout(const PsRasterDesc* d, PsRasterStateLayout* out) {
   if (!desc_ok(d) || !out) return PS_ERR_BAD_ARG;
   *out = make_state_layout(*d);
@@ -74,7 +77,7 @@ namespace {
 struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
   float* final_T; uint32_t* n_contrib; uint32_t* tile_end; uint32_t* tile_ranges;
-  uint32_t* num_rendered; uint32_t* tile_order;
+  uint32_t* num_rendered; uint32_t* tile_order; uint32_t* inv_slots;
   uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *bin_counts;
 };
 FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
@@ -89,6 +92,7 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.tile_ranges = (uint32_t*)(sb + L.tile_ranges);
   p.num_rendered = (uint32_t*)(sb + L.num_rendered);
   p.tile_order = (uint32_t*)(sb + L.tile_order);
+  p.inv_slots = (uint32_t*)(sb + L.inv_slots);
   p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
   p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
   p.block_hist = (uint32_t*)(tb + T.block_hist); p.bin_counts = (uint32_t*)(tb + T.bin_counts);
@@ -148,7 +152,7 @@ int ps_raster_forward_render(const PsRasterDesc* d, const float* view_params, fl
   {
     Scope sc(G_BINS, st);
     launch_bin_write(*d, p.sorted_rect, p.sorted_idx, p.n_vis, p.bin_counts, p.tile_ranges,
-                     p.num_rendered, point_list, cap, st);
+                     p.num_rendered, point_list, p.inv_slots, cap, st);
   }
   {
     Scope sc(G_TILES_FWD, st);
@@ -187,34 +191,37 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   if (!sh && !dL_dcolors) return PS_ERR_BAD_ARG;
   const Dims m = make_dims(*d);
   const PsRasterStateLayout L = make_state_layout(*d);
-  const TempLayout T = make_temp_layout(*d);
+  const uint32_t capacity = clamp_capacity(list_capacity);
+  if (!point_list && capacity > 0) return PS_ERR_BAD_ARG;
+  const BwdTempLayout T = make_bwd_temp_layout(*d, capacity);
   if (state_bytes < L.total || temp_bytes < T.total) return PS_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const char* sb = (const char*)state; char* tb = (char*)temp;
   const float* records = (const float*)(sb + L.records);
+  const uint2* rects = (const uint2*)(sb + L.rects);
   const uint32_t* tile_ranges = (const uint32_t*)(sb + L.tile_ranges);
   const uint32_t* tile_order = (const uint32_t*)(sb + L.tile_order);
-  const uint32_t capacity = clamp_capacity(list_capacity);
-  if (!point_list && capacity > 0) return PS_ERR_BAD_ARG;
+  const uint32_t* inv_slots = (const uint32_t*)(sb + L.inv_slots);
   const float* final_T = (const float*)(sb + L.final_T);
   const uint32_t* n_contrib = (const uint32_t*)(sb + L.n_contrib);
   const uint32_t* tile_end = (const uint32_t*)(sb + L.tile_end);
   float* grad2d = (float*)(tb + T.grad2d);
+  float* tile_grads = (float*)(tb + T.tile_grads);
   {
     Scope sc(G_MEMSET, st);
-    if (hipMemsetAsync(grad2d, 0, m.N * kGradFloats * 4, st) != hipSuccess) return PS_ERR_LAUNCH;
+    // one memset covers grad2d (atomic path) and the per-(tile, entry) slots
+    if (hipMemsetAsync(tb, 0, T.total, st) != hipSuccess) return PS_ERR_LAUNCH;
   }
   {
     Scope sc(G_TILES_BWD, st);
     launch_tiles_backward(*d, records, tile_order, tile_ranges, point_list, capacity, view_params,
-                          final_T,
-                          n_contrib, tile_end, dL_dcolor, grad2d, st);
+                          final_T, n_contrib, tile_end, dL_dcolor, grad2d, tile_grads, st);
   }
   {
     Scope sc(G_PRE_BWD, st);
-    launch_preprocess_backward(*d, means, cov, sh, view_params, records, radii, grad2d,
-                               dL_dmeans, dL_dcov, dL_dsh, dL_dcolors, dL_dopacity, dL_dmeans2D,
-                               st);
+    launch_preprocess_backward(*d, means, cov, sh, view_params, records, radii, rects, inv_slots,
+                               tile_grads, capacity, grad2d, dL_dmeans, dL_dcov, dL_dsh,
+                               dL_dcolors, dL_dopacity, dL_dmeans2D, st);
   }
   return check_launch();
 }

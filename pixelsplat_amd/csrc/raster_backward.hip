@@ -22,7 +22,10 @@ namespace ps {
 __global__ void __launch_bounds__(256)
 geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
                          const float* __restrict__ cov, const float* __restrict__ view_params,
-                         const int32_t* __restrict__ radii, const float* __restrict__ grad2d,
+                         const int32_t* __restrict__ radii, const uint2* __restrict__ rects,
+                         const uint32_t* __restrict__ inv_slots,
+                         const float* __restrict__ tile_grads, uint32_t capacity,
+                         float* __restrict__ grad2d,
                          float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov,
                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
                          float* __restrict__ dL_dmeans2D) {
@@ -51,7 +54,34 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
     const int v = s * vps + j;
     const size_t vg = (size_t)v * G + g;
     const bool vis = radii[vg] > 0;
-    const float* gr = grad2d + vg * kGradFloats;
+    float gr[kGradFloats];
+#pragma unroll
+    for (int c = 0; c < kGradFloats; ++c) gr[c] = 0.f;
+    if (vis) {
+      // Gaussians touching <= 4 tiles: sum their private (tile, entry) slots in tile order
+      // (deterministic); larger ones were accumulated with atomics into grad2d
+      const uint2 r = rects[vg];
+      const uint32_t area = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
+      if (area <= (uint32_t)kInvSlots) {
+        for (uint32_t k = 0; k < area; ++k) {
+          const uint32_t pos = inv_slots[vg * kInvSlots + k];
+          if (pos < capacity) {
+            const float4* tg = reinterpret_cast<const float4*>(tile_grads + (size_t)pos * kSlotFloats);
+            const float4 t0 = tg[0], t1 = tg[1];
+            const float t2 = tile_grads[(size_t)pos * kSlotFloats + 8];
+            gr[0] += t0.x; gr[1] += t0.y; gr[2] += t0.z; gr[3] += t0.w;
+            gr[4] += t1.x; gr[5] += t1.y; gr[6] += t1.z; gr[7] += t1.w; gr[8] += t2;
+          }
+        }
+        // the SH backward kernel reads the colour gradient from grad2d
+        float* go = grad2d + vg * kGradFloats;
+        go[6] = gr[6]; go[7] = gr[7]; go[8] = gr[8];
+      } else {
+        const float* gi = grad2d + vg * kGradFloats;
+#pragma unroll
+        for (int c = 0; c < kGradFloats; ++c) gr[c] = gi[c];
+      }
+    }
     if (dL_dmeans2D) {
       float* o = dL_dmeans2D + vg * 3;
       o[0] = vis ? gr[0] : 0.f;
@@ -289,14 +319,16 @@ color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
 
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
-                                const int32_t* radii, const float* grad2d, float* dL_dmeans,
+                                const int32_t* radii, const uint2* rects,
+                                const uint32_t* inv_slots, const float* tile_grads,
+                                uint32_t capacity, float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st) {
   {
     dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
     hipLaunchKernelGGL(geometry_backward_kernel, grid, block, 0, st, d, means, cov, view_params,
-                       radii, grad2d, dL_dmeans, dL_dcov, sh ? (float*)nullptr : dL_dcolors,
-                       dL_dopacity, dL_dmeans2D);
+                       radii, rects, inv_slots, tile_grads, capacity, grad2d, dL_dmeans, dL_dcov,
+                       sh ? (float*)nullptr : dL_dcolors, dL_dopacity, dL_dmeans2D);
   }
   if (!sh) return;
   const int deg = d.sh_degree;

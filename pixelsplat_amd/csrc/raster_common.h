@@ -13,6 +13,8 @@ constexpr int kTile = 16;               // 16x16 pixel tiles (bin parity with th
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 constexpr int kRecFloats = 12;          // one 48-byte record per (view, gaussian)
 constexpr int kGradFloats = 9;          // dxy(2) dconic(3) dopacity(1) drgb(3)
+constexpr int kSlotFloats = 12;         // per-(tile, entry) gradient slot: 9 used, 48-byte aligned
+constexpr int kInvSlots = 4;            // Gaussians touching <= 4 tiles use slots, larger ones atomics
 
 // sort geometry
 constexpr int kSortThreads = 256;
@@ -61,6 +63,16 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
   return t;
 }
 
+struct BwdTempLayout { size_t grad2d, tile_grads, total; };
+inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_capacity) {
+  const Dims m = make_dims(d);
+  BwdTempLayout t; size_t o = 0;
+  t.grad2d = o; o = align_up(o + m.N * kGradFloats * 4);
+  t.tile_grads = o; o = align_up(o + list_capacity * kSlotFloats * 4);
+  t.total = o;
+  return t;
+}
+
 inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   Dims m = make_dims(d);
   PsRasterStateLayout s; size_t o = 0;
@@ -75,6 +87,7 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.tile_ranges = o; o = align_up(o + (size_t)m.V * m.tiles * 8);
   s.num_rendered = o; o = align_up(o + 8);
   s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
+  s.inv_slots = o; o = align_up(o + m.N * kInvSlots * 4);
   s.total = o;
   return s;
 }
@@ -94,8 +107,8 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
                       uint32_t* tile_order, hipStream_t st);
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
                       const uint32_t* n_vis, uint32_t* counts, const uint32_t* tile_ranges,
-                      uint32_t* num_rendered, uint32_t* point_list, uint32_t capacity,
-                      hipStream_t st);
+                      uint32_t* num_rendered, uint32_t* point_list, uint32_t* inv_slots,
+                      uint32_t capacity, hipStream_t st);
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* tile_order, const uint32_t* tile_ranges,
@@ -109,11 +122,14 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const uint32_t* tile_end,
-                           const float* dL_dcolor, float* grad2d, hipStream_t st);
+                           const float* dL_dcolor, float* grad2d, float* tile_grads,
+                           hipStream_t st);
 
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
-                                const int32_t* radii, const float* grad2d, float* dL_dmeans,
+                                const int32_t* radii, const uint2* rects,
+                                const uint32_t* inv_slots, const float* tile_grads,
+                                uint32_t capacity, float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st);
 

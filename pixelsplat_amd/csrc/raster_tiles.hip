@@ -19,6 +19,8 @@
 // /root/reference/src/model/decoder/cuda_splatting.py:117-124).
 #include "raster_common.h"
 
+#include <cstdlib>
+
 namespace ps {
 
 constexpr int kBatch = 64;
@@ -181,9 +183,15 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   };
 
   auto blend = [&](uint32_t m) {
+    // software pipeline: entry j+1's record is fetched from LDS while entry j is blended
+    float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
+           n2 = lds.rec[b_head & (kQB - 1)][2];
     for (uint32_t j = 0; j < m; ++j) {
-      const uint32_t slot = (b_head + j) & (kQB - 1);
-      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const float4 q0 = n0, q1 = n1, q2 = n2;
+      {
+        const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
+        n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
+      }
       const uint32_t hidx = __float_as_uint(q2.y);
       const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #pragma unroll
@@ -294,7 +302,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const float* __restrict__ view_params, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib,
                       const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
-                      float* __restrict__ grad2d) {
+                      float* __restrict__ grad2d, float* __restrict__ tile_grads) {
   __shared__ WaveLdsBwd lds_all[kWavesPerBlock];
   const int G = d.n_gaussians, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
@@ -358,7 +366,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       keep = qm != 0u;
       q0 = make_float4(r0.x, r0.y, A, B);
       q1 = make_float4(Cq, r1.y, r2.x, r2.y);
-      q2 = make_float4(r2.z, __uint_as_float(top - lane), __uint_as_float(qm),
+      // bit 4: the Gaussian touches <= 4 tiles -> its partial gradient goes to a private slot
+      const uint32_t small = (uint32_t)__float_as_int(r1.w) <= (uint32_t)kInvSlots ? 16u : 0u;
+      q2 = make_float4(r2.z, __uint_as_float(top - lane), __uint_as_float(qm | small),
                        __uint_as_float(id));
     }
     const uint64_t mask = __ballot(keep);
@@ -371,9 +381,14 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   };
 
   auto blend = [&](uint32_t m) {
+    float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
+           n2 = lds.rec[b_head & (kQB - 1)][2];
     for (uint32_t j = 0; j < m; ++j) {
-      const uint32_t slot = (b_head + j) & (kQB - 1);
-      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const float4 q0 = n0, q1 = n1, q2 = n2;
+      {
+        const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
+        n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
+      }
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
       const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
@@ -390,8 +405,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
           const bool ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
           const float ale = ok ? alpha : 0.f;              // 0 => all updates are no-ops
           const float oma = 1.f - ale;
-          float rcp = __builtin_amdgcn_rcpf(oma);
-          rcp = fmaf(fmaf(-oma, rcp, 1.f), rcp, rcp);      // one Newton step: ~0.5 ulp
+          const float rcp = __builtin_amdgcn_rcpf(oma);   // 1 ulp; exact 1 when ale == 0
           const float Tn = T[k] * rcp;                      // T in front of this entry
           const float d0 = c0 - acc0[k], d1 = c1 - acc1[k], d2 = c2 - acc2[k];
           float dL_dalpha = (d0 * g0[k] + d1 * g1[k] + d2 * g2[k]) * Tn;
@@ -411,7 +425,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
           any |= ok;
         }
       }
-      if (__any(any)) {
+      if (__any(any) && !(d.reserved & 1)) {
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         wave_sum9_to_lane63(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b);
         if (lane == 63) {
@@ -425,23 +439,29 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     }
     wave_lds_sync();
     // lane j finalises entry j: one set of 9 atomics per (tile, Gaussian)
-    if ((uint32_t)lane < m && lds.gsum[lane][9] != 0.f) {
+    if ((uint32_t)lane < m && lds.gsum[lane][9] != 0.f && !(d.reserved & 2)) {
       const uint32_t slot = (b_head + lane) & (kQB - 1);
       const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
       const float* gs = lds.gsum[lane];
       const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
                   cz = q1.x * (-2.f / kLog2e);
       const float Mx = gs[0], My = gs[1];
-      float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
-      atomicAdd(ga + 0, (-cx * Mx - cy * My) * ddelx_dx);
-      atomicAdd(ga + 1, (-cz * My - cy * Mx) * ddely_dy);
-      atomicAdd(ga + 2, -0.5f * gs[2]);
-      atomicAdd(ga + 3, -0.5f * gs[3]);
-      atomicAdd(ga + 4, -0.5f * gs[4]);
-      atomicAdd(ga + 5, gs[5]);
-      atomicAdd(ga + 6, gs[6]);
-      atomicAdd(ga + 7, gs[7]);
-      atomicAdd(ga + 8, gs[8]);
+      const float o0 = (-cx * Mx - cy * My) * ddelx_dx, o1 = (-cz * My - cy * Mx) * ddely_dy;
+      const float o2 = -0.5f * gs[2], o3 = -0.5f * gs[3], o4 = -0.5f * gs[4];
+      if (__float_as_uint(q2.z) & 16u) {
+        // private slot of this (tile, entry): plain 16-byte stores, summed later in a fixed
+        // order by the geometry backward (no atomics, deterministic)
+        const uint32_t pos = l_start + __float_as_uint(q2.y) - 1u;
+        float4* tg = reinterpret_cast<float4*>(tile_grads + (size_t)pos * kSlotFloats);
+        tg[0] = make_float4(o0, o1, o2, o3);
+        tg[1] = make_float4(o4, gs[5], gs[6], gs[7]);
+        tg[2] = make_float4(gs[8], 0.f, 0.f, 0.f);
+      } else {
+        float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
+        atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
+        atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, gs[5]);
+        atomicAdd(ga + 6, gs[6]); atomicAdd(ga + 7, gs[7]); atomicAdd(ga + 8, gs[8]);
+      }
     }
     b_head += m;
     wave_lds_sync();
@@ -461,14 +481,17 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const uint32_t* tile_end,
-                           const float* dL_dcolor, float* grad2d, hipStream_t st) {
+                           const float* dL_dcolor, float* grad2d, float* tile_grads,
+                           hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order,
+  PsRasterDesc dd = d;
+  if (const char* e = getenv("PS_DEBUG_BWD")) dd.reserved = atoi(e);   // perf experiments only
+  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, dd, records, tile_order,
                      tile_ranges,
                      point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
-                     grad2d);
+                     grad2d, tile_grads);
 }
 
 }  // namespace ps

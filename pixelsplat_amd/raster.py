@@ -183,7 +183,8 @@ class _Rasterize(torch.autograd.Function):
         g_colors = torch.empty_like(colors) if colors is not None else None
         g_m2d = (torch.empty((V, cfg.n_gaussians, 3), dtype=torch.float32, device=dev)
                  if ctx.has_means2d else None)
-        temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+        temp = torch.empty(lib.ps_raster_backward_temp_bytes(C.byref(d), plist.numel()),
+                           dtype=torch.uint8, device=dev)
         _lib.check(lib.ps_raster_backward(
             C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
             _p(radii), _p(dL_dcolor), _p(state), state.numel(), _p(temp), temp.numel(),
