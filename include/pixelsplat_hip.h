@@ -168,6 +168,16 @@ int ps_raster_backward(const PsRasterDesc* desc, const float* means, const float
 int ps_raster_check(const PsRasterDesc* desc, const void* state, size_t state_bytes,
                     uint64_t* num_rendered, void* stream);
 
+/* Camera set-up for n_views views in one launch: everything render_cuda computes on the host
+ * side before it calls the rasterizer (cuda_splatting.py:64-71 renorm by 1/near when
+ * scale_invariant != 0, :80-82 tan(fov/2) from the normalised intrinsics, :17-44 projection,
+ * :84-87 transposed view / full-projection, :110 camera position) -> view_params[V][48].
+ *   extrinsics float[V][4][4] camera-to-world, intrinsics float[V][3][3], near/far float[V],
+ *   bg float[V][3]. */
+int ps_camera_setup(int32_t n_views, const float* extrinsics, const float* intrinsics,
+                    const float* near, const float* far, const float* bg,
+                    int32_t scale_invariant, float* view_params, void* stream);
+
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents
  * on the caller's stream; ps_profile_collect synchronises those events, ADDS the elapsed

@@ -226,6 +226,16 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   return check_launch();
 }
 
+int ps_camera_setup(int32_t n_views, const float* extrinsics, const float* intrinsics,
+                    const float* near, const float* far, const float* bg,
+                    int32_t scale_invariant, float* view_params, void* stream) {
+  if (n_views <= 0 || !extrinsics || !intrinsics || !near || !far || !bg || !view_params)
+    return PS_ERR_BAD_ARG;
+  launch_camera_setup(n_views, extrinsics, intrinsics, near, far, bg, scale_invariant,
+                      view_params, (hipStream_t)stream);
+  return check_launch();
+}
+
 int ps_raster_check(const PsRasterDesc* d, const void* state, size_t state_bytes,
                     uint64_t* num_rendered, void* stream) {
   if (!desc_ok(d) || !state) return PS_ERR_BAD_ARG;

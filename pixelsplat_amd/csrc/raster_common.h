@@ -133,6 +133,10 @@ void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st);
 
+void launch_camera_setup(int n_views, const float* extrinsics, const float* intrinsics,
+                         const float* near, const float* far, const float* bg,
+                         int scale_invariant, float* view_params, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 

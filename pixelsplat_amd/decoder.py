@@ -37,7 +37,34 @@ class DecoderOutput:
     depth: Tensor | None   # [batch, view, height, width]
 
 
-def _view_params(extrinsics, near, far, fov_x, fov_y, tan_fov, background_color, scale):
+def camera_setup(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                 background_color: Tensor, scale_invariant: bool = True) -> Tensor:
+    """[V,4,4] c2w, [V,3,3], [V], [V], [V,3] -> packed view parameters [V,48] in ONE HIP
+    launch (ps_camera_setup): the renorm, field of view, projection, transposed view /
+    full-projection matrices and camera position of cuda_splatting.py:64-87,110."""
+    import ctypes as C
+
+    from . import _lib
+    from .raster import _p, _stream
+
+    lib = _lib.load()
+    v = extrinsics.shape[0]
+    e = extrinsics.contiguous().float()
+    k = intrinsics.contiguous().float()
+    n, f = near.contiguous().float(), far.contiguous().float()
+    bg = background_color.contiguous().float()
+    if not e.is_cuda:
+        raise RuntimeError("pixelsplat_amd needs GPU tensors (no CPU fallback)")
+    out = torch.empty((v, 48), dtype=torch.float32, device=e.device)
+    _lib.check(lib.ps_camera_setup(C.c_int32(v), _p(e), _p(k), _p(n), _p(f), _p(bg),
+                                   C.c_int32(int(scale_invariant)), _p(out), _stream()),
+               "ps_camera_setup")
+    return out
+
+
+def _view_params_torch(extrinsics, near, far, fov_x, fov_y, tan_fov, background_color, scale):
+    """PyTorch composition of the same block (only the orthographic visualisation path uses
+    it: its field of view is prescribed, not derived from intrinsics)."""
     projection = get_projection_matrix(near, far, fov_x, fov_y).transpose(1, 2)
     view = torch.linalg.inv(extrinsics).transpose(1, 2)
     full = view @ projection
@@ -45,17 +72,15 @@ def _view_params(extrinsics, near, far, fov_x, fov_y, tan_fov, background_color,
                             background_color, scale)
 
 
-def _render(extrinsics, near, far, fov_x, fov_y, tan_fov, image_shape, background_color,
-            gaussian_means, gaussian_covariances, gaussian_sh_coefficients, gaussian_opacities,
-            scale, use_sh, views_per_scene, return_aux):
+def _render(vp, image_shape, gaussian_means, gaussian_covariances, gaussian_sh_coefficients,
+            gaussian_opacities, use_sh, views_per_scene, return_aux):
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
-    v_total = extrinsics.shape[0]
+    v_total = vp.shape[0]
     s, g, _ = gaussian_means.shape
     assert s * views_per_scene == v_total, "views must be grouped by scene"
     h, w = image_shape
     n = gaussian_sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
-    vp = _view_params(extrinsics, near, far, fov_x, fov_y, tan_fov, background_color, scale)
     cfg = RasterConfig(n_scenes=s, views_per_scene=views_per_scene, n_gaussians=g, height=h,
                        width=w, sh_degree=degree if use_sh else 0, sh_coeffs=n if use_sh else 0,
                        sh_layout=PS_SH_G3K, cov_layout=PS_COV_33)
@@ -89,19 +114,10 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
 
     With views_per_scene == 1 the call is argument-for-argument the reference's
     render_cuda (Gaussians given once per view)."""
-    if scale_invariant:
-        scale = 1 / near
-        extrinsics = extrinsics.clone()
-        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
-        near = near * scale
-        far = far * scale
-    else:
-        scale = torch.ones_like(near)
-    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
-    tan_fov = torch.stack(((0.5 * fov_x).tan(), (0.5 * fov_y).tan()), dim=-1)
-    return _render(extrinsics, near, far, fov_x, fov_y, tan_fov, image_shape, background_color,
-                   gaussian_means, gaussian_covariances, gaussian_sh_coefficients,
-                   gaussian_opacities, scale, use_sh, views_per_scene, return_aux)
+    vp = camera_setup(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    return _render(vp, image_shape, gaussian_means, gaussian_covariances,
+                   gaussian_sh_coefficients, gaussian_opacities, use_sh, views_per_scene,
+                   return_aux)
 
 
 def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor,
@@ -131,10 +147,10 @@ def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, 
         dump["far"] = far
     fov_xb = fov_x.expand(b)
     tan_fov = torch.stack((tan_fov_x.expand(b), tan_fov_y.expand(b)), dim=-1)
-    return _render(extrinsics, near, far, fov_xb, fov_y.expand(b), tan_fov, image_shape,
-                   background_color, gaussian_means, gaussian_covariances,
-                   gaussian_sh_coefficients, gaussian_opacities, torch.ones_like(near), use_sh,
-                   views_per_scene, False)
+    vp = _view_params_torch(extrinsics, near, far, fov_xb, fov_y.expand(b), tan_fov,
+                            background_color, torch.ones_like(near))
+    return _render(vp, image_shape, gaussian_means, gaussian_covariances,
+                   gaussian_sh_coefficients, gaussian_opacities, use_sh, views_per_scene, False)
 
 
 def render_depth_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,

@@ -215,3 +215,30 @@ def test_empty_and_degenerate(gpu_device):
     st = R.forward(dtype=np.float32, **sc)
     img, radii, _ = _single_view_hip(sc, gpu_device)
     assert np.array_equal(radii, st.radii) and np.abs(img - st.image).max() < IMG_TOL
+
+
+def test_camera_setup_matches_reference_host_math(gpu_device):
+    """ps_camera_setup vs the PyTorch restatement of cuda_splatting.py:64-87 (geometry.py)."""
+    from pixelsplat_amd.decoder import camera_setup
+    from pixelsplat_amd.geometry import camera_matrices
+
+    ctx, tgt, g, _ = make_workload(3, (64, 64), seed=4)
+    V = 12
+    ext = tgt.extrinsics.reshape(V, 4, 4).clone()
+    ext[:, :3, :3] = torch.linalg.qr(ext[:, :3, :3] + 0.1 * torch.randn(V, 3, 3))[0]
+    intr = tgt.intrinsics.reshape(V, 3, 3).clone()
+    intr[:, 0, 0] = 0.7
+    intr[:, 0, 2] = 0.45
+    near, far = tgt.near.reshape(V), tgt.far.reshape(V)
+    bg = torch.rand(V, 3)
+    vp = camera_setup(ext.to(gpu_device), intr.to(gpu_device), near.to(gpu_device),
+                      far.to(gpu_device), bg.to(gpu_device)).cpu()
+    scale = 1 / near
+    e2 = ext.clone()
+    e2[:, :3, 3] *= scale[:, None]
+    tanfov, view_t, full_t, campos = camera_matrices(e2, intr, near * scale, far * scale)
+    assert torch.allclose(vp[:, 0:16], view_t.reshape(V, 16), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(vp[:, 16:32], full_t.reshape(V, 16), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(vp[:, 32:35], campos, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(vp[:, 35:37], tanfov, rtol=1e-5)
+    assert torch.allclose(vp[:, 37:40], bg) and torch.allclose(vp[:, 40], scale)
