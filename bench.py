@@ -37,36 +37,15 @@ def parse():
     p.add_argument("--size", type=int, default=256)
     p.add_argument("--views", type=int, default=4, help="target views per scene")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-views", type=int, default=4, help="views in the CPU-baseline sample")
+    p.add_argument("--cpu-views", type=int, default=16, help="views in the CPU-baseline sample")
     return p.parse_args()
-
-
-def init_dist(n):
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    return rank, world, local
-
-
-def barrier(world):
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
 
 
 def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     """The oracle (CPU port of the same algorithm) timed on the host cores over a bounded
-    sample of the same workload: the first `n_views` views of scene 0, forward + backward.
-    Also the parity figure: L_inf / PSNR of the GPU render against the oracle render."""
+    sample of the same workload: the first `n_views` views of the batch (scene-major),
+    forward + backward.  Also the parity figure: L_inf / PSNR of the GPU render against the
+    oracle render of the same views."""
     import numpy as np
     from oracle import raster_ref as R
     from tests.cases import oracle_view_inputs
@@ -76,8 +55,9 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     cores = os.cpu_count() or 1
     t_total = 0.0
     linf, mse = 0.0, []
+    vps = tgt.near.shape[1]
     for v in range(n_views):
-        inp = oracle_view_inputs(gaussians, tgt, 0, v, view_params=vps_np[v])
+        inp = oracle_view_inputs(gaussians, tgt, v // vps, v % vps, view_params=vps_np[v])
         t0 = time.perf_counter()
         st = R.forward(H=hw[0], W=hw[1], **inp)
         R.backward(st, dL[v])
@@ -89,7 +69,7 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     m = float(np.mean(mse))
     psnr = float("inf") if m == 0 else -10.0 * float(np.log10(m))
     return dict(value=n_views / t_total, unit="views/s", cores=cores, kind="port",
-                sample=f"scene 0, first {n_views} of {tgt.near.shape[1]} target views, "
+                sample=f"first {n_views} of {tgt.near.numel()} views of the step (scene-major), "
                        f"{hw[0]}x{hw[1]}, G={gaussians.means.shape[1]}, fwd+bwd, "
                        f"oracle/raster_ref.c with OpenMP on {cores} threads, {t_total:.1f} s"), \
         dict(linf=linf, psnr_db=psnr if psnr != float("inf") else 999.0)
@@ -97,7 +77,9 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
 
 def main():
     args = parse()
-    rank, world, local = init_dist(args.gpus)
+    from pixelsplat_amd import parallel as P
+
+    rank, world, local = P.init_from_env()
     dev = torch.device("cuda", local)
 
     from pixelsplat_amd import _lib
@@ -108,7 +90,7 @@ def main():
     lib = _lib.load()  # raises if the HIP library is missing: no fallback
     hw = (args.size, args.size)
     b, v = args.batch, args.views
-    ctx, tgt, g, target = make_workload(b, hw, v_ctx=2, v_tgt=v, seed=rank)
+    ctx, tgt, g, target = make_workload(b, hw, v_ctx=2, v_tgt=v, seed=P.rank_seed(0, rank))
     G = g.means.shape[1]
     V = b * v
 
@@ -147,24 +129,20 @@ def main():
     ng = lib.ps_profile_group_count()
     tot_ms = (C.c_double * ng)()
     launches = (C.c_int64 * ng)()
-    barrier(world)
+    P.barrier(world)
     lib.ps_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier(world)
+    P.barrier(world)
     elapsed = time.perf_counter() - t0
     lib.ps_profile_enable(0)
     _lib.check(lib.ps_profile_collect(tot_ms, launches), "ps_profile_collect")
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = P.max_over_ranks(elapsed, world, dev)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * V * args.steps / elapsed
+        value = P.aggregate_throughput(V, args.steps, world, elapsed)
         groups = {lib.ps_profile_group_name(i).decode(): (tot_ms[i] / max(launches[i], 1),
                                                           int(launches[i])) for i in range(ng)}
         # algorithmic bytes per launch (DESIGN.md "kernels"): the reference-algorithm figure of
@@ -173,6 +151,7 @@ def main():
         alg = {
             "preprocess_forward": 392.0 * G * V,
             "depth_sort": 48.0 * D_total,
+            "tile_bins": 0.0,
             "tiles_forward": 36.0 * D_total + 20.0 * P * V,
             "tiles_backward": 76.0 * D_total + 20.0 * P * V,
             "preprocess_backward": 728.0 * G * V,
@@ -208,14 +187,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             dL = (2.0 * (torch.from_numpy(gpu_images) - target.reshape(V, 3, *hw))
                   / gpu_images.size).numpy()
-            nv = min(args.cpu_views, v)
+            nv = min(args.cpu_views, V)
             cb, parity = cpu_baseline(g, tgt, vps_np, hw, nv, gpu_images, dL)
             out["cpu_baseline"] = cb
             out["parity_vs_oracle"] = parity
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    P.shutdown(world)
 
 
 if __name__ == "__main__":
