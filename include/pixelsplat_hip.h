@@ -178,6 +178,29 @@ int ps_camera_setup(int32_t n_views, const float* extrinsics, const float* intri
                     const float* near, const float* far, const float* bg,
                     int32_t scale_invariant, float* view_params, void* stream);
 
+/* ---- (A) epipolar sampler ------------------------------------------------------------
+ * Sampling geometry of EpipolarSampler.forward + get_depth + depth_to_relative_disparity
+ * (/root/reference/src/model/encoder/epipolar/epipolar_sampler.py:51-123,
+ *  src/geometry/epipolar_lines.py:157-292, src/geometry/projection.py:74-137,176-230,
+ *  src/model/encoder/epipolar/conversions.py:17-27) for all (batch, view, other view, ray)
+ * in one launch.  Rays are the h x w pixel centres of the (down-scaled) feature grid.
+ *   c2w, w2c   float[b][v][4][4]  camera-to-world and its inverse (row-major)
+ *   k, k_inv   float[b][v][3][3]  normalised intrinsics and inverse
+ *   near, far  float[b][v]
+ *   origins, directions float[b][v][h*w][3]
+ *   segments   float[b][v][v-1][h*w][6] = xy_min(2), xy_max(2), t_min, t_max
+ *   flags      uint8[b][v][v-1][h*w]: bit0 overlaps_image, bit1 near-point valid, bit2
+ *              far-point valid, bits3-4 frame selector (min t), bits5-6 selector (max t)
+ *   xy_sample  float[b][v][v-1][h*w][s][2]
+ *   depth      float[b][v][v-1][h*w][s]  (unclipped), rel_disparity same shape (clipped to
+ *              [near, far], then 1 - (1/d - 1/far)/(1/near - 1/far))
+ * Other view index: index_v[v][ov] = ov < v ? ov : ov + 1 (heterogeneous_pairings.py:9-24). */
+int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
+                         const float* c2w, const float* w2c, const float* k,
+                         const float* k_inv, const float* near, const float* far,
+                         float* origins, float* directions, float* segments, uint8_t* flags,
+                         float* xy_sample, float* depth, float* rel_disparity, void* stream);
+
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents
  * on the caller's stream; ps_profile_collect synchronises those events, ADDS the elapsed

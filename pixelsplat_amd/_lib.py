@@ -42,7 +42,7 @@ EXPORTS = [
     "ps_raster_backward_temp_bytes",
     "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
     "ps_raster_forward_render", "ps_raster_backward",
-    "ps_raster_check", "ps_camera_setup", "ps_status_string", "ps_build_info",
+    "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_status_string", "ps_build_info",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
 ]
 
@@ -91,6 +91,8 @@ def load():
     lib.ps_raster_backward.restype = C.c_int
     lib.ps_camera_setup.argtypes = [C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, vp]
     lib.ps_camera_setup.restype = C.c_int
+    lib.ps_epipolar_geometry.argtypes = [C.c_int32] * 5 + [vp] * 13 + [vp]
+    lib.ps_epipolar_geometry.restype = C.c_int
     lib.ps_raster_check.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t,
                                     C.POINTER(C.c_uint64), vp]
     lib.ps_raster_check.restype = C.c_int

@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "libpixelsplat_hip.so")
 # tile rect, depth key): no FMA contraction there so the bins are bit-reproducible.
 SOURCES = [
     ("raster_preprocess.hip", ["-ffp-contract=off"]),
+    ("epipolar_geometry.hip", ["-ffp-contract=off"]),
     ("raster_sort.hip", []),
     ("raster_tiles.hip", []),
     ("raster_backward.hip", []),

@@ -236,6 +236,21 @@ int ps_camera_setup(int32_t n_views, const float* extrinsics, const float* intri
   return check_launch();
 }
 
+int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
+                         const float* c2w, const float* w2c, const float* k,
+                         const float* k_inv, const float* near, const float* far,
+                         float* origins, float* directions, float* segments, uint8_t* flags,
+                         float* xy_sample, float* depth, float* rel_disparity, void* stream) {
+  if (b <= 0 || v < 2 || h <= 0 || w <= 0 || s <= 0) return PS_ERR_BAD_ARG;
+  if (!c2w || !w2c || !k || !k_inv || !near || !far || !origins || !directions || !segments ||
+      !flags || !xy_sample || !depth || !rel_disparity)
+    return PS_ERR_BAD_ARG;
+  launch_epipolar_geometry(b, v, h, w, s, c2w, w2c, k, k_inv, near, far, origins, directions,
+                           segments, flags, xy_sample, depth, rel_disparity,
+                           (hipStream_t)stream);
+  return check_launch();
+}
+
 int ps_raster_check(const PsRasterDesc* d, const void* state, size_t state_bytes,
                     uint64_t* num_rendered, void* stream) {
   if (!desc_ok(d) || !state) return PS_ERR_BAD_ARG;

@@ -137,6 +137,12 @@ void launch_camera_setup(int n_views, const float* extrinsics, const float* intr
                          const float* near, const float* far, const float* bg,
                          int scale_invariant, float* view_params, hipStream_t st);
 
+void launch_epipolar_geometry(int b, int v, int h, int w, int s, const float* c2w,
+                              const float* w2c, const float* kmat, const float* kinv,
+                              const float* near, const float* far, float* origins,
+                              float* directions, float* seg, uint8_t* flags, float* xy_sample,
+                              float* depth, float* rel_disp, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
