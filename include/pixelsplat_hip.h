@@ -201,6 +201,39 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
                          float* origins, float* directions, float* segments, uint8_t* flags,
                          float* xy_sample, float* depth, float* rel_disparity, void* stream);
 
+/* Fused epipolar gather + single-query cross-attention with folded key/value projections
+ * (replaces F.grid_sample at epipolar_sampler.py:98-104, the depth-encoding add at
+ * epipolar_transformer.py:113-121 and Attention.forward(x, z=kv) at attention.py:54-70; the
+ * dense 128x128 folds stay plain GEMMs on the host side).  R = b*v*h*w rays, T = s*(v-1)
+ * tokens per ray in the reference's "(s ov)" order, P = 2*octaves.
+ *   fmap   float[b*v][h][w][c]   feature maps, channels-last
+ *   xy_sample, flags, rel_disparity: outputs of ps_epipolar_geometry
+ *   qt     float[R][heads][c]    q~_h = W_k,h^T q_h        u float[R][heads][P] = W_d^T q~_h
+ *   e      float[R][heads][v-1]  q~_h . view_embedding[perm[ov]], or NULL
+ * forward outputs  fbar[R][heads][c] = sum_i a_i feat_i, pbar[R][heads][P] = sum_i a_i pe_i,
+ *                  abar[R][heads][v-1] = attention mass per other view, attn[R][heads][T].
+ * backward inputs  dfbar, dpbar, dabar (same shapes); outputs dqt, du, de, ds (scratch
+ *                  [R][heads][T]) and dfmap float[b*v][h][w][c] (written, not accumulated;
+ *                  may be NULL).  No global atomics: the feature-map gradient is built in
+ *                  LDS, one channel slice of one image per workgroup. */
+typedef struct PsEpipolarDesc {
+  int32_t b, v, h, w, s, c, heads, octaves;
+} PsEpipolarDesc;
+int ps_epipolar_gather(const PsEpipolarDesc* desc, const float* fmap, const float* xy_sample,
+                       const uint8_t* flags, float* features /*[b][v][v-1][h*w][s][c]*/,
+                       void* stream);
+int ps_epipolar_attention_forward(const PsEpipolarDesc* desc, const float* fmap,
+                                  const float* xy_sample, const uint8_t* flags,
+                                  const float* rel_disparity, const float* qt, const float* u,
+                                  const float* e, float scale, float* fbar, float* pbar,
+                                  float* abar, float* attn, void* stream);
+int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap,
+                                   const float* xy_sample, const uint8_t* flags,
+                                   const float* rel_disparity, const float* qt,
+                                   const float* attn, const float* dfbar, const float* dpbar,
+                                   const float* dabar, float scale, float* dqt, float* du,
+                                   float* de, float* ds, float* dfmap, void* stream);
+
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents
  * on the caller's stream; ps_profile_collect synchronises those events, ADDS the elapsed

@@ -36,13 +36,18 @@ class PsRasterStateLayout(C.Structure):
         "tile_end", "tile_ranges", "num_rendered", "tile_order", "inv_slots", "total")]
 
 
+class PsEpipolarDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("b", "v", "h", "w", "s", "c", "heads", "octaves")]
+
+
 # every symbol include/pixelsplat_hip.h declares
 EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
     "ps_raster_backward_temp_bytes",
     "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
     "ps_raster_forward_render", "ps_raster_backward",
-    "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_status_string", "ps_build_info",
+    "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
+    "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
 ]
 
@@ -93,6 +98,13 @@ def load():
     lib.ps_camera_setup.restype = C.c_int
     lib.ps_epipolar_geometry.argtypes = [C.c_int32] * 5 + [vp] * 13 + [vp]
     lib.ps_epipolar_geometry.restype = C.c_int
+    pe = C.POINTER(PsEpipolarDesc)
+    lib.ps_epipolar_gather.argtypes = [pe, vp, vp, vp, vp, vp]
+    lib.ps_epipolar_gather.restype = C.c_int
+    lib.ps_epipolar_attention_forward.argtypes = [pe] + [vp] * 7 + [C.c_float] + [vp] * 5
+    lib.ps_epipolar_attention_forward.restype = C.c_int
+    lib.ps_epipolar_attention_backward.argtypes = [pe] + [vp] * 9 + [C.c_float] + [vp] * 6
+    lib.ps_epipolar_attention_backward.restype = C.c_int
     lib.ps_raster_check.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t,
                                     C.POINTER(C.c_uint64), vp]
     lib.ps_raster_check.restype = C.c_int

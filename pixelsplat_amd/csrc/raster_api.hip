@@ -251,6 +251,56 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
   return check_launch();
 }
 
+namespace {
+bool epi_ok(const PsEpipolarDesc* d) {
+  return d && d->b > 0 && d->v >= 2 && d->h > 0 && d->w > 0 && d->s > 0 && d->c > 0 &&
+         d->heads > 0 && d->octaves > 0;
+}
+AttnDims to_dims(const PsEpipolarDesc* d) {
+  return AttnDims{d->b, d->v, d->h, d->w, d->s, d->c, d->heads, d->octaves};
+}
+}  // namespace
+
+int ps_epipolar_gather(const PsEpipolarDesc* d, const float* fmap, const float* xy_sample,
+                       const uint8_t* flags, float* features, void* stream) {
+  if (!epi_ok(d) || !fmap || !xy_sample || !flags || !features) return PS_ERR_BAD_ARG;
+  if (int rc = launch_epipolar_gather(to_dims(d), fmap, xy_sample, flags, features,
+                                      (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_epipolar_attention_forward(const PsEpipolarDesc* d, const float* fmap,
+                                  const float* xy_sample, const uint8_t* flags,
+                                  const float* rel_disparity, const float* qt, const float* u,
+                                  const float* e, float scale, float* fbar, float* pbar,
+                                  float* abar, float* attn, void* stream) {
+  if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !u || !fbar ||
+      !pbar || !abar || !attn)
+    return PS_ERR_BAD_ARG;
+  if (int rc = launch_epipolar_attn_forward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
+                                            qt, u, e, scale, fbar, pbar, abar, attn,
+                                            (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
+                                   const float* xy_sample, const uint8_t* flags,
+                                   const float* rel_disparity, const float* qt,
+                                   const float* attn, const float* dfbar, const float* dpbar,
+                                   const float* dabar, float scale, float* dqt, float* du,
+                                   float* de, float* ds, float* dfmap, void* stream) {
+  if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !dfbar ||
+      !dpbar || !dabar || !dqt || !du || !de || !ds)
+    return PS_ERR_BAD_ARG;
+  if (int rc = launch_epipolar_attn_backward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
+                                             qt, attn, dfbar, dpbar, dabar, scale, dqt, du, de,
+                                             ds, dfmap, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
 int ps_raster_check(const PsRasterDesc* d, const void* state, size_t state_bytes,
                     uint64_t* num_rendered, void* stream) {
   if (!desc_ok(d) || !state) return PS_ERR_BAD_ARG;

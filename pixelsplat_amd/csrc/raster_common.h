@@ -143,6 +143,19 @@ void launch_epipolar_geometry(int b, int v, int h, int w, int s, const float* c2
                               float* directions, float* seg, uint8_t* flags, float* xy_sample,
                               float* depth, float* rel_disp, hipStream_t st);
 
+struct AttnDims { int b, v, h, w, s, c, heads, octaves; };
+int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* xy,
+                           const uint8_t* flags, float* out, hipStream_t st);
+int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const float* xy,
+                                 const uint8_t* flags, const float* rd, const float* qt,
+                                 const float* u, const float* e, float scale, float* fbar,
+                                 float* pbar, float* abar, float* attn, hipStream_t st);
+int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const float* xy,
+                                  const uint8_t* flags, const float* rd, const float* qt,
+                                  const float* attn, const float* dfbar, const float* dpbar,
+                                  const float* dabar, float scale, float* dqt, float* du,
+                                  float* de, float* ds, float* dfmap, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 

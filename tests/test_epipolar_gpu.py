@@ -84,3 +84,103 @@ def test_degenerate_cameras(gpu_device):
     assert torch.equal(g.overlaps.cpu(), ref.segment.overlaps)
     assert torch.equal(g.xy_sample.cpu(), ref.xy_sample)
     assert torch.isfinite(g.rel_disparity).all()
+
+
+def _golden(name):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+
+
+@pytest.mark.parametrize("name", ["epipolar_v2.npz", "epipolar_v3.npz"])
+def test_fused_attention_vs_reference_golden(gpu_device, name):
+    """Golden vectors produced by the REAL reference (sampler, get_depth, depth encoding,
+    PreNorm(Attention(x, z=kv)) + residual): fused HIP path vs the reference's numbers."""
+    from pixelsplat_amd.epipolar import fused_cross_attention, gather_features, sample_geometry
+
+    g = _golden(name)
+    dev = gpu_device
+    feat = g["features_in"].to(dev)
+    b, v, c, h, w = feat.shape
+    s, heads = int(g["num_samples"]), int(g["heads"])
+    geo = sample_geometry(g["extrinsics"].to(dev), g["intrinsics"].to(dev), g["near"].to(dev),
+                          g["far"].to(dev), (h, w), s,
+                          w2c=torch.linalg.inv(g["extrinsics"]).to(dev),
+                          k_inv=torch.linalg.inv(g["intrinsics"]).to(dev))
+    assert torch.equal(geo.xy_sample.cpu(), g["xy_sample"])
+    assert torch.equal(geo.overlaps.cpu(), g["overlaps"])
+    fmap = feat.permute(0, 1, 3, 4, 2).contiguous()
+    sampled = gather_features(fmap, geo)
+    assert (sampled.cpu() - g["sampled"]).abs().max() < 5e-6
+    x = feat.permute(0, 1, 3, 4, 2).reshape(-1, 1, c)
+    xn = torch.nn.functional.layer_norm(x, (c,), g["attn.norm.weight"].to(dev),
+                                        g["attn.norm.bias"].to(dev))
+    y, attn = fused_cross_attention(
+        xn, fmap, geo, w_q=g["attn.fn.to_q.weight"].to(dev), w_kv=g["attn.fn.to_kv.weight"].to(dev),
+        w_out=g["attn.fn.to_out.0.weight"].to(dev), b_out=g["attn.fn.to_out.0.bias"].to(dev),
+        heads=heads, depth_w=g["depth_w"].to(dev), depth_b=g["depth_b"].to(dev), octaves=10,
+        return_attn=True)
+    # noise floor: the depth -> PE branch amplifies fp32 round-off by up to 2 pi 2^9
+    # (SURVEY.md Appendix B step 12); measured reference fp32-vs-fp64 ~1e-3 on these inputs
+    assert (attn.cpu() - g["attn_weights"]).abs().max() < 5e-3
+    assert ((y + x).cpu() - g["attn_out"]).abs().max() < 5e-3
+
+
+def test_fused_attention_vs_oracle_and_autograd(gpu_device):
+    """Same rel_disparity on both sides (so the PE noise amplification drops out): forward to
+    1e-5 and every gradient (features, q path, depth-encoding weights, to_kv / to_out)
+    against torch autograd through the oracle's unfused restatement."""
+    from pixelsplat_amd.epipolar import fused_cross_attention, sample_geometry
+
+    torch.manual_seed(0)
+    b, v, c, h, w, s, heads, dh = 2, 3, 16, 6, 8, 4, 2, 8
+    ctx = _cams(b, v, 5)
+    feat = torch.randn(b, v, c, h, w)
+    dev = gpu_device
+    geo = sample_geometry(ctx.extrinsics.to(dev), ctx.intrinsics.to(dev), ctx.near.to(dev),
+                          ctx.far.to(dev), (h, w), s,
+                          w2c=torch.linalg.inv(ctx.extrinsics).to(dev),
+                          k_inv=torch.linalg.inv(ctx.intrinsics).to(dev))
+    inner = heads * dh
+    P = dict(w_q=torch.randn(inner, c) * 0.3, w_kv=torch.randn(2 * inner, c) * 0.3,
+             w_out=torch.randn(c, inner) * 0.3, b_out=torch.randn(c) * 0.1,
+             depth_w=torch.randn(c, 20) * 0.3, depth_b=torch.randn(c) * 0.1,
+             view_emb=torch.randn(v - 1, c) * 0.3)
+    x = torch.randn(b * v * h * w, 1, c)
+    gout = torch.randn(b * v * h * w, 1, c)
+
+    def run(device, fused):
+        leaves = {k: t.clone().to(device).requires_grad_(True) for k, t in P.items()}
+        f = feat.clone().to(device).requires_grad_(True)
+        xx = x.clone().to(device).requires_grad_(True)
+        fmap = f.permute(0, 1, 3, 4, 2).contiguous()
+        if fused:
+            y = fused_cross_attention(xx, fmap, geo, heads=heads, octaves=10, **leaves)
+        else:
+            xy = geo.xy_sample.cpu()
+            sampled = torch.stack([torch.stack([torch.stack([
+                E.gather_features(f[bi, int(E.heterogeneous_index(v)[vi, oi])],
+                                  xy[bi, vi, oi].reshape(-1, 2)).reshape(h * w, s, c)
+                for oi in range(v - 1)]) for vi in range(v)]) for bi in range(b)])
+            sampled = sampled * geo.overlaps.cpu()[..., None, None]
+            enc = E.positional_encoding(geo.rel_disparity.cpu(), 10) @ leaves["depth_w"].T \
+                + leaves["depth_b"]
+            kv = sampled + enc + leaves["view_emb"][None, None, :, None, None, :]
+            z = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, s * (v - 1), c)
+            q = xx @ leaves["w_q"].T
+            k_, v_ = (z @ leaves["w_kv"].T).chunk(2, dim=-1)
+            sp = lambda t: t.reshape(t.shape[0], -1, heads, dh).transpose(1, 2)
+            a = ((sp(q) @ sp(k_).transpose(-1, -2)) * dh ** -0.5).softmax(-1)
+            y = (a @ sp(v_)).transpose(1, 2).reshape(-1, 1, inner) @ leaves["w_out"].T \
+                + leaves["b_out"]
+        (y * gout.to(device)).sum().backward()
+        grads = {k: t.grad.cpu() for k, t in leaves.items()}
+        grads["feat"], grads["x"] = f.grad.cpu(), xx.grad.cpu()
+        return y.detach().cpu(), grads
+
+    y_ref, g_ref = run("cpu", False)
+    y_hip, g_hip = run(dev, True)
+    assert (y_hip - y_ref).abs().max() < 2e-5 * max(1.0, y_ref.abs().max().item())
+    for k in g_ref:
+        scale = g_ref[k].abs().max().item()
+        assert (g_hip[k] - g_ref[k]).abs().max() < 1e-4 * max(scale, 1e-3), k
