@@ -1,0 +1,8 @@
+"""Drop-in mirrors of the reference's epipolar encoder modules (path A), same class names,
+constructor arguments, parameter / buffer names (released checkpoints load unchanged) and
+return types; the sampler geometry, feature gather and cross-attention run on the HIP
+kernels of libpixelsplat_hip.so."""
+from .epipolar_sampler import EpipolarSampler, EpipolarSampling  # noqa: F401
+from .epipolar_transformer import (EpipolarTransformer, EpipolarTransformerCfg,  # noqa: F401
+                                   ImageSelfAttentionCfg)
+from .transformer import Attention, FeedForward, PreNorm, Transformer  # noqa: F401

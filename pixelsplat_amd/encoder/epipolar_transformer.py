@@ -1,0 +1,198 @@
+"""EpipolarTransformer mirror
+(/root/reference/src/model/encoder/epipolar/epipolar_transformer.py:20-183,
+ image_self_attention.py:13-79, src/model/encodings/positional_encoding.py:8-36).
+
+Same constructor `(cfg, d_in)`, same parameter names (depth_encoding.1, transformer.layers.*,
+downscaler, upscaler, upscale_refinement.*, view_embeddings) and the same return value
+`(features, sampling)`.  The hot part -- sampler geometry, depth, depth encoding, feature
+gather and the two cross-attention layers -- runs on the HIP kernels; kv
+([b,v,ov,r,s,c], 0.94 GB at the paper config) is never materialised.  When a visualiser
+hooks `layer[0].fn.attend` (encoder_visualizer_epipolar.py:52-56) the layer falls back to
+the unfused formulation on a materialised kv so the hook sees the softmax output.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from functools import partial
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from ..epipolar import fused_cross_attention, gather_features
+from .epipolar_sampler import EpipolarSampler, EpipolarSampling
+from .transformer import Transformer
+
+
+@dataclass
+class ImageSelfAttentionCfg:
+    patch_size: int
+    num_octaves: int
+    num_layers: int
+    num_heads: int
+    d_token: int
+    d_dot: int
+    d_mlp: int
+
+
+@dataclass
+class EpipolarTransformerCfg:
+    self_attention: ImageSelfAttentionCfg
+    num_octaves: int
+    num_layers: int
+    num_heads: int
+    num_samples: int
+    d_dot: int
+    d_mlp: int
+    downscale: int
+
+
+class PositionalEncoding(nn.Module):
+    """sin(x * 2 pi 2^k + {0, pi/2}) for values in [0, 1] (positional_encoding.py:8-36)."""
+
+    def __init__(self, num_octaves: int):
+        super().__init__()
+        octaves = torch.arange(num_octaves).float()
+        frequencies = (2 * torch.pi * 2 ** octaves)[:, None].expand(num_octaves, 2).contiguous()
+        self.register_buffer("frequencies", frequencies, persistent=False)
+        phases = torch.tensor([0, 0.5 * torch.pi], dtype=torch.float32)
+        self.register_buffer("phases", phases[None].expand(num_octaves, 2).contiguous(),
+                             persistent=False)
+
+    def forward(self, samples: Tensor) -> Tensor:
+        x = samples[..., None, None] * self.frequencies
+        return torch.sin(x + self.phases).flatten(-3)
+
+    def d_out(self, dimensionality: int) -> int:
+        return self.frequencies.numel() * dimensionality
+
+
+class ImageSelfAttention(nn.Module):
+    def __init__(self, cfg: ImageSelfAttentionCfg, d_in: int, d_out: int):
+        super().__init__()
+        self.positional_encoding = nn.Sequential(
+            (pe := PositionalEncoding(cfg.num_octaves)), nn.Linear(pe.d_out(2), cfg.d_token))
+        self.patch_embedder = nn.Sequential(
+            nn.Conv2d(d_in, cfg.d_token, cfg.patch_size, cfg.patch_size), nn.ReLU())
+        self.transformer = Transformer(cfg.d_token, cfg.num_layers, cfg.num_heads, cfg.d_dot,
+                                       cfg.d_mlp)
+        self.resampler = nn.ConvTranspose2d(cfg.d_token, d_out, cfg.patch_size, cfg.patch_size)
+
+    def forward(self, image: Tensor) -> Tensor:
+        tokens = self.patch_embedder(image)
+        _, _, nh, nw = tokens.shape
+        ys, xs = torch.meshgrid(torch.arange(nh, device=image.device),
+                                torch.arange(nw, device=image.device), indexing="ij")
+        xy = torch.stack(((xs + 0.5) / nw, (ys + 0.5) / nh), -1).float()
+        tokens = tokens + self.positional_encoding(xy).permute(2, 0, 1)
+        b, c = tokens.shape[:2]
+        tokens = self.transformer(tokens.flatten(2).transpose(1, 2))
+        tokens = tokens.transpose(1, 2).reshape(b, c, nh, nw)
+        return self.resampler(tokens)
+
+
+class ImageSelfAttentionWrapper(nn.Module):
+    def __init__(self, self_attention_cfg: ImageSelfAttentionCfg, d_in: int, d_hidden: int,
+                 dropout: float):
+        super().__init__()
+        self.self_attention = ImageSelfAttention(self_attention_cfg, d_in, d_in)
+
+    def forward(self, x: Tensor, b: int, v: int, h: int, w: int) -> Tensor:
+        c = x.shape[-1]
+        img = x.reshape(b * v, h, w, c).permute(0, 3, 1, 2)
+        img = self.self_attention(img) + img
+        return img.permute(0, 2, 3, 1).reshape(b * v * h * w, 1, c)
+
+
+def _num_context_views_from_reference_cfg() -> Optional[int]:
+    try:  # running inside the reference: src/global_cfg.py (epipolar_transformer.py:46)
+        from src.global_cfg import get_cfg  # type: ignore
+
+        return int(get_cfg().dataset.view_sampler.num_context_views)
+    except Exception:
+        return None
+
+
+class EpipolarTransformer(nn.Module):
+    cfg: EpipolarTransformerCfg
+
+    def __init__(self, cfg: EpipolarTransformerCfg, d_in: int,
+                 num_context_views: Optional[int] = None) -> None:
+        super().__init__()
+        if num_context_views is None:
+            num_context_views = _num_context_views_from_reference_cfg()
+        if num_context_views is None:
+            raise ValueError("num_context_views not given and the reference global cfg is absent")
+        self.cfg = cfg
+        self.epipolar_sampler = EpipolarSampler(num_context_views, cfg.num_samples)
+        if cfg.num_octaves > 0:
+            self.depth_encoding = nn.Sequential(
+                (pe := PositionalEncoding(cfg.num_octaves)), nn.Linear(pe.d_out(1), d_in))
+        feed_forward_layer = partial(ImageSelfAttentionWrapper, cfg.self_attention)
+        self.transformer = Transformer(d_in, cfg.num_layers, cfg.num_heads, cfg.d_dot, cfg.d_mlp,
+                                       selfatt=False, kv_dim=d_in,
+                                       feed_forward_layer=feed_forward_layer)
+        self.downscaler = self.upscaler = self.upscale_refinement = None
+        if cfg.downscale:
+            self.downscaler = nn.Conv2d(d_in, d_in, cfg.downscale, cfg.downscale)
+            self.upscaler = nn.ConvTranspose2d(d_in, d_in, cfg.downscale, cfg.downscale)
+            self.upscale_refinement = nn.Sequential(
+                nn.Conv2d(d_in, d_in * 2, 7, 1, 3), nn.GELU(), nn.Conv2d(d_in * 2, d_in, 7, 1, 3))
+        if num_context_views > 2:
+            self.view_embeddings = nn.Embedding(num_context_views, d_in)
+
+    def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
+                far: Tensor, materialize_sampling: bool = False,
+                view_shuffle: Optional[Tensor] = None) -> tuple[Tensor, EpipolarSampling]:
+        if self.cfg.num_octaves <= 0:
+            raise NotImplementedError("the fused path always adds the depth encoding "
+                                      "(every reference config has num_octaves = 10)")
+        b, v, c, _, _ = features.shape
+        if self.downscaler is not None:
+            features = self.downscaler(features.flatten(0, 1)).unflatten(0, (b, v))
+        _, _, _, h, w = features.shape
+        sampler = self.epipolar_sampler
+        geo = sampler.geometry(extrinsics, intrinsics, near, far, (h, w))
+        fmap = features.permute(0, 1, 3, 4, 2).contiguous()          # channels-last
+
+        view_emb = None
+        if v > 2:   # randomly permuted per-view embeddings (epipolar_transformer.py:126-131)
+            if view_shuffle is None:
+                view_shuffle = torch.randperm(v - 1, device=features.device)
+            view_emb = self.view_embeddings(view_shuffle)
+
+        lin = self.depth_encoding[1]
+        hooked = any(len(layer[0].fn.attend._forward_hooks) > 0 for layer in self.transformer.layers)
+        need_kv = hooked or materialize_sampling
+        sampled = gather_features(fmap, geo) if need_kv else None
+        sampling = sampler.sampling_from_geometry(geo, (h, w), sampled)
+
+        x = fmap.reshape(b * v * h * w, 1, c)
+        kv = None
+        for attn, ff in self.transformer.layers:
+            a = attn.fn
+            if len(a.attend._forward_hooks) > 0:
+                if kv is None:   # unfused formulation so the hook sees the attention weights
+                    kv = sampled + self.depth_encoding(geo.rel_disparity[..., None])
+                    if view_emb is not None:
+                        kv = kv + view_emb[None, None, :, None, None, :]
+                    kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
+                y = attn(x, z=kv)
+            else:
+                to_out = a.to_out[0] if isinstance(a.to_out, nn.Sequential) else None
+                y = fused_cross_attention(
+                    attn.norm(x), fmap, geo, w_q=a.to_q.weight, w_kv=a.to_kv.weight,
+                    w_out=(to_out.weight if to_out is not None else
+                           torch.eye(c, device=x.device, dtype=x.dtype)),
+                    b_out=(to_out.bias if to_out is not None else None), heads=a.heads,
+                    depth_w=lin.weight, depth_b=lin.bias, octaves=self.cfg.num_octaves,
+                    view_emb=view_emb)
+            x = y + x
+            x = ff(x, b=b, v=v, h=h, w=w) + x
+        features = x.reshape(b, v, h, w, c).permute(0, 1, 4, 2, 3)
+
+        if self.upscaler is not None:
+            f = self.upscaler(features.flatten(0, 1))
+            f = self.upscale_refinement(f) + f
+            features = f.unflatten(0, (b, v))
+        return features, sampling

@@ -1,0 +1,47 @@
+"""Golden vectors of the REFERENCE's full EpipolarTransformer.forward (small config), with its
+state_dict, for the drop-in module test.  Run in the build container:
+    python tests/golden/make_transformer_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_import as RI  # noqa: E402
+from pixelsplat_amd.synthetic import make_cameras  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CFG = dict(num_octaves=10, num_layers=2, num_heads=2, num_samples=4, d_dot=8, d_mlp=32, downscale=2)
+SA = dict(patch_size=2, num_octaves=4, num_layers=1, num_heads=2, d_token=16, d_dot=8, d_mlp=32)
+
+
+def one(name, v, seed):
+    m = RI.modules(v)
+    cfg = m.transformer.EpipolarTransformerCfg(
+        self_attention=m.self_attention.ImageSelfAttentionCfg(**SA), **CFG)
+    torch.manual_seed(seed)
+    net = m.transformer.EpipolarTransformer(cfg, 16)
+    gen = torch.Generator().manual_seed(seed)
+    ctx, _ = make_cameras(1, v, 4, (256, 256), gen)
+    feat = torch.randn((1, v, 16, 16, 16), generator=gen)
+    torch.manual_seed(100 + seed)
+    shuffle = torch.randperm(v - 1)
+    torch.manual_seed(100 + seed)
+    out, samp = net(feat, ctx.extrinsics, ctx.intrinsics, ctx.near, ctx.far)
+    sd = {"sd." + k: t.detach().numpy() for k, t in net.state_dict().items()}
+    np.savez_compressed(
+        os.path.join(HERE, name), features_in=feat.numpy(), extrinsics=ctx.extrinsics.numpy(),
+        intrinsics=ctx.intrinsics.numpy(), near=ctx.near.numpy(), far=ctx.far.numpy(),
+        shuffle=shuffle.numpy(), out=out.detach().numpy(), valid=samp.valid.numpy(),
+        xy_sample=samp.xy_sample.numpy(), xy_sample_near=samp.xy_sample_near.numpy(),
+        xy_sample_far=samp.xy_sample_far.numpy(), xy_ray=samp.xy_ray.numpy(),
+        sampled=samp.features.detach().numpy(), **sd)
+    print(name, out.shape, len(sd), "tensors")
+
+
+if __name__ == "__main__":
+    one("transformer_v2.npz", 2, 0)
+    one("transformer_v3.npz", 3, 1)
