@@ -214,8 +214,10 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
  *                  abar[R][heads][v-1] = attention mass per other view, attn[R][heads][T].
  * backward inputs  dfbar, dpbar, dabar (same shapes); outputs dqt, du, de, ds (scratch
  *                  [R][heads][T]) and dfmap float[b*v][h][w][c] (written, not accumulated;
- *                  may be NULL).  No global atomics: the feature-map gradient is built in
- *                  LDS, one channel slice of one image per workgroup. */
+ *                  may be NULL; needs ray_boxes, a uint32[b*v*(v-1)*h*w] scratch).  No atomics
+ *                  of any kind: one wave owns a 4x4 pixel tile of the gradient image in LDS,
+ *                  so the result is bit-reproducible.  Limits: c % 4 == 0, c <= 256,
+ *                  heads <= 4, T <= 128, h, w <= 255 for the gradient. */
 typedef struct PsEpipolarDesc {
   int32_t b, v, h, w, s, c, heads, octaves;
 } PsEpipolarDesc;
@@ -232,7 +234,8 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap
                                    const float* rel_disparity, const float* qt,
                                    const float* attn, const float* dfbar, const float* dpbar,
                                    const float* dabar, float scale, float* dqt, float* du,
-                                   float* de, float* ds, float* dfmap, void* stream);
+                                   float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
+                                   void* stream);
 
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents

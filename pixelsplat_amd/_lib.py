@@ -103,7 +103,7 @@ def load():
     lib.ps_epipolar_gather.restype = C.c_int
     lib.ps_epipolar_attention_forward.argtypes = [pe] + [vp] * 7 + [C.c_float] + [vp] * 5
     lib.ps_epipolar_attention_forward.restype = C.c_int
-    lib.ps_epipolar_attention_backward.argtypes = [pe] + [vp] * 9 + [C.c_float] + [vp] * 6
+    lib.ps_epipolar_attention_backward.argtypes = [pe] + [vp] * 9 + [C.c_float] + [vp] * 7
     lib.ps_epipolar_attention_backward.restype = C.c_int
     lib.ps_raster_check.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t,
                                     C.POINTER(C.c_uint64), vp]

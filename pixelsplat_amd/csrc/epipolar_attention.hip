@@ -89,14 +89,35 @@ __device__ __forceinline__ void gather(const float* __restrict__ img, int h, int
   add(xin1 && yin1, k.x0 + 1, k.y0 + 1, w11);
 }
 
+// sin(x) for x in [0, ~4000]: two-constant Cody-Waite reduction to [-pi/4, pi/4] (the FMA
+// keeps n*C exact) and the cephes sinf/cosf polynomials; |error| < 2e-7.  libm's sinf costs
+// ~150 instructions at these magnitudes, this ~25.
+__device__ __forceinline__ float sin_reduced(float x) {
+  const float n = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-n, 1.5707963705062866f, x);
+  r = fmaf(-n, -4.3711388286737929e-8f, r);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f),
+                        z * r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                             4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)n;
+  const float v = (q & 1) ? cp : sp;
+  return (q & 2) ? -v : v;
+}
+
 __device__ __forceinline__ float pe_value(float rd, int p) {
   // sin(rd * 2 pi 2^(p/2) + (p & 1) pi/2)   (positional_encoding.py:14-33).  The product is
   // rounded before the phase is added, as in the reference: at 2 pi 2^9 an FMA would move
   // the argument by up to 1.2e-4.
-#pragma clang fp contract(off)
   const float freq = 6.2831854820251465f * (float)(1 << (p >> 1));
   const float phase = (p & 1) ? 1.5707963705062866f : 0.0f;
-  return sinf(rd * freq + phase);
+  float arg;
+  {
+#pragma clang fp contract(off)
+    arg = rd * freq + phase;
+  }
+  return sin_reduced(arg);
 }
 
 // ------------------------------------------------------------------------------------
@@ -129,9 +150,240 @@ epipolar_gather_kernel(AttnDims dm, const float* __restrict__ fmap,
 }
 
 // ------------------------------------------------------------------------------------
-// attention forward
+// fused attention, one wave64 per ray
 // ------------------------------------------------------------------------------------
-template <int CPL>
+// Wave-private LDS (floats): feat [T][c+4] | pe [T][Ps] | token records [T][8] | rd [T].
+// The row strides (c+4, Ps) are odd multiples of 4 floats so that the 128-bit reads of the
+// token-per-lane passes are bank-conflict free.
+//
+// Lane roles change between phases, which is what keeps the kernel off the VALU-issue floor
+// (the first version did everything lanes<->channels and spent its time in per-token
+// cross-lane reductions and 20-lane sinf calls):
+//   A  lanes <-> tokens    token record: 4 clamped corner pixels + 4 bilinear weights
+//   B  lanes <-> (t, p)    positional encoding, all 64 lanes busy
+//   C  lanes <-> (t, 4 ch) gather, 64/LPT tokens per step, 16-byte loads
+//   D  lanes <-> tokens    scores: the folded query sits in SGPRs (uniform per ray), a lane
+//                          walks its token's row in LDS -- no cross-lane reduction at all
+//   E  lanes <-> tokens    softmax with two DPP reductions for all heads at once
+//   F  lanes <-> channels  context: the weights come out of the token lanes with v_readlane
+struct RayCtx {
+  int ray, r, v, ovn, T, P, Ps, cs, H;
+  size_t bv, bbase;
+  float *featS, *peS, *tokS, *rdS;
+};
+
+__host__ __device__ inline int pe_stride(int P) {
+  int ps = (P + 3) & ~3;
+  if (((ps >> 2) & 1) == 0) ps += 4;
+  return ps;
+}
+__host__ __device__ inline size_t wave_lds_floats(int T, int c, int P) {
+  return (size_t)T * (c + 4 + pe_stride(P) + 8 + 1);
+}
+
+#define PS_DPPMAX4(ctrl)                     \
+  "v_max_f32_dpp %0, %0, %0 " ctrl "\n"      \
+  "v_max_f32_dpp %1, %1, %1 " ctrl "\n"      \
+  "v_max_f32_dpp %2, %2, %2 " ctrl "\n"      \
+  "v_max_f32_dpp %3, %3, %3 " ctrl "\n"
+// wave64 maxima of four values (results in lane 63).  No bound_ctrl: a lane whose DPP source
+// is outside its row keeps its own value, which is the identity for max.
+__device__ __forceinline__ void wave_max4_to_lane63(float& a, float& b, float& c, float& d) {
+  asm volatile(
+      "s_nop 1\n"
+      PS_DPPMAX4("row_shr:1 row_mask:0xf bank_mask:0xf")
+      PS_DPPMAX4("row_shr:2 row_mask:0xf bank_mask:0xf")
+      PS_DPPMAX4("row_shr:4 row_mask:0xf bank_mask:0xf")
+      PS_DPPMAX4("row_shr:8 row_mask:0xf bank_mask:0xf")
+      PS_DPPMAX4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      PS_DPPMAX4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 1\n"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef PS_DPPMAX4
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// phases A-C: fills the wave's LDS with the gathered tokens and their encodings
+template <int LPT>
+__device__ __forceinline__ void stage_tokens(const AttnDims& dm, const RayCtx& k, int lane,
+                                             const float* __restrict__ fmap,
+                                             const float* __restrict__ xy,
+                                             const uint8_t* __restrict__ flags,
+                                             const float* __restrict__ rd) {
+  const int R = dm.h * dm.w;
+  // A
+  for (int t = lane; t < k.T; t += kWave) {
+    const int si = t / k.ovn, ov = t - si * k.ovn;
+    const size_t ro = (k.bv * k.ovn + ov) * R + k.r;
+    const size_t so = ro * dm.s + si;
+    const int src = (int)k.bbase + (ov < k.v ? ov : ov + 1);
+    const bool ok = flags[ro] & 1;
+    const float2 p = *reinterpret_cast<const float2*>(xy + 2 * so);
+    const Corner cq = corner_of(p.x, p.y, dm.w, dm.h);
+    const bool xin0 = cq.x0 >= 0 && cq.x0 < dm.w, xin1 = cq.x0 + 1 >= 0 && cq.x0 + 1 < dm.w;
+    const bool yin0 = cq.y0 >= 0 && cq.y0 < dm.h, yin1 = cq.y0 + 1 >= 0 && cq.y0 + 1 < dm.h;
+    const int xa = min(max(cq.x0, 0), dm.w - 1), xb = min(max(cq.x0 + 1, 0), dm.w - 1);
+    const int ya = min(max(cq.y0, 0), dm.h - 1), yb = min(max(cq.y0 + 1, 0), dm.h - 1);
+    const int base = src * R;
+    int4 off = make_int4(base + ya * dm.w + xa, base + ya * dm.w + xb, base + yb * dm.w + xa,
+                         base + yb * dm.w + xb);
+    float4 wt;
+    wt.x = (ok && xin0 && yin0) ? (1.f - cq.wx) * (1.f - cq.wy) : 0.f;
+    wt.y = (ok && xin1 && yin0) ? cq.wx * (1.f - cq.wy) : 0.f;
+    wt.z = (ok && xin0 && yin1) ? (1.f - cq.wx) * cq.wy : 0.f;
+    wt.w = (ok && xin1 && yin1) ? cq.wx * cq.wy : 0.f;
+    *reinterpret_cast<int4*>(k.tokS + t * 8) = off;
+    *reinterpret_cast<float4*>(k.tokS + t * 8 + 4) = wt;
+    k.rdS[t] = rd[so];
+  }
+  wave_lds_sync();
+  // B
+  const float inv_p = 1.0f / (float)k.P;
+  for (int idx = lane; idx < k.T * k.P; idx += kWave) {
+    const int t = (int)(((float)idx + 0.5f) * inv_p);
+    const int p = idx - t * k.P;
+    k.peS[t * k.Ps + p] = pe_value(k.rdS[t], p);
+  }
+  // C
+  constexpr int TPI = kWave / LPT;
+  const int lt = lane / LPT, ch = (lane % LPT) * 4;
+#pragma unroll 2
+  for (int t0 = 0; t0 < k.T; t0 += TPI) {
+    const int t = t0 + lt;
+    if (t < k.T && ch < dm.c) {
+      const int4 off = *reinterpret_cast<const int4*>(k.tokS + t * 8);
+      const float4 wt = *reinterpret_cast<const float4*>(k.tokS + t * 8 + 4);
+      const float4 p0 = *reinterpret_cast<const float4*>(fmap + (size_t)off.x * dm.c + ch);
+      const float4 p1 = *reinterpret_cast<const float4*>(fmap + (size_t)off.y * dm.c + ch);
+      const float4 p2 = *reinterpret_cast<const float4*>(fmap + (size_t)off.z * dm.c + ch);
+      const float4 p3 = *reinterpret_cast<const float4*>(fmap + (size_t)off.w * dm.c + ch);
+      float4 f;
+      f.x = fmaf(p3.x, wt.w, fmaf(p2.x, wt.z, fmaf(p1.x, wt.y, p0.x * wt.x)));
+      f.y = fmaf(p3.y, wt.w, fmaf(p2.y, wt.z, fmaf(p1.y, wt.y, p0.y * wt.x)));
+      f.z = fmaf(p3.z, wt.w, fmaf(p2.z, wt.z, fmaf(p1.z, wt.y, p0.z * wt.x)));
+      f.w = fmaf(p3.w, wt.w, fmaf(p2.w, wt.z, fmaf(p1.w, wt.y, p0.w * wt.x)));
+      *reinterpret_cast<float4*>(k.featS + t * k.cs + ch) = f;
+    }
+  }
+  wave_lds_sync();
+}
+
+// phase D: out[g][h] = qrow_h . feat_t + urow_h . pe_t + erow_{h, ov(t)} for token
+// t = lane + 64 g.  qrow/urow/erow are wave-uniform pointers (scalar loads).
+__device__ __forceinline__ void token_scores(const AttnDims& dm, const RayCtx& k, int lane,
+                                             const float* __restrict__ qrow,
+                                             const float* __restrict__ urow,
+                                             const float* __restrict__ erow,
+                                             float (&out)[2][kMaxHeads]) {
+  int hsel[kMaxHeads];
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) hsel[hh] = hh < k.H ? hh : 0;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) out[g][hh] = 0.f;
+    if (g * kWave >= k.T) continue;                       // uniform
+    const int t = min(lane + g * kWave, k.T - 1);
+    const float* frow = k.featS + t * k.cs;
+    float acc[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int ch = 0; ch < dm.c; ch += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(frow + ch);
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh) {
+        const float* qp = qrow + hsel[hh] * dm.c + ch;
+        acc[hh] = fmaf(qp[3], f.w, fmaf(qp[2], f.z, fmaf(qp[1], f.y, fmaf(qp[0], f.x, acc[hh]))));
+      }
+    }
+    const float* prow = k.peS + t * k.Ps;
+    for (int p = 0; p < k.P; ++p) {
+      const float pe = prow[p];
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] = fmaf(urow[hsel[hh] * k.P + p], pe, acc[hh]);
+    }
+    if (erow != nullptr) {
+      const int ov = t % k.ovn;
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] += erow[hsel[hh] * k.ovn + ov];
+    }
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) out[g][hh] = acc[hh];
+  }
+}
+
+// phase F: rows[h][:] = sum_t wgt_{h,t} feat_t, prow[h][:] = sum_t wgt pe_t,
+// orow[h][ov] = sum_{t: ov(t)=ov} wgt  (orow may be null)
+template <int LPT>
+__device__ __forceinline__ void weighted_context(const AttnDims& dm, const RayCtx& k, int lane,
+                                                 const float (&wgt)[2][kMaxHeads],
+                                                 float* __restrict__ rows,
+                                                 float* __restrict__ prow,
+                                                 float* __restrict__ orow) {
+  constexpr int CPL = LPT >= 16 ? LPT / 16 : 1;
+  const int c0 = lane * CPL;
+  const bool lane_c = c0 < dm.c;
+  float acc[kMaxHeads][CPL], pacc[kMaxHeads], oacc[kMaxHeads];
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) {
+    pacc[hh] = 0.f; oacc[hh] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[hh][i] = 0.f;
+  }
+  const int fo = lane_c ? c0 : 0, po = lane < k.P ? lane : 0;
+  int ov = 0;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int cnt = min(k.T - g * kWave, kWave);
+    for (int tl = 0; tl < cnt; ++tl) {
+      const int t = g * kWave + tl;
+      float f[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) f[i] = k.featS[t * k.cs + fo + i];
+      const float pe = k.peS[t * k.Ps + po];
+      const bool mine = ov == lane;
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh) {
+        const float a = lane_bcast(wgt[g][hh], tl);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) acc[hh][i] = fmaf(a, f[i], acc[hh][i]);
+        pacc[hh] = fmaf(a, pe, pacc[hh]);
+        if (orow != nullptr) oacc[hh] += mine ? a : 0.f;
+      }
+      ov = ov + 1 == k.ovn ? 0 : ov + 1;
+    }
+  }
+  for (int hh = 0; hh < k.H; ++hh) {
+    if (lane_c) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) rows[(size_t)hh * dm.c + c0 + i] = acc[hh][i];
+    }
+    if (lane < k.P) prow[hh * k.P + lane] = pacc[hh];
+    if (orow != nullptr && lane < k.ovn) orow[hh * k.ovn + lane] = oacc[hh];
+  }
+}
+
+__device__ __forceinline__ bool ray_setup(const AttnDims& dm, float* smem, RayCtx& k) {
+  const int R = dm.h * dm.w;
+  k.ovn = dm.v - 1; k.T = dm.s * k.ovn; k.P = 2 * dm.octaves; k.Ps = pe_stride(k.P);
+  k.cs = dm.c + 4; k.H = dm.heads;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  k.ray = (int)blockIdx.x * kAttnWaves + wv;
+  if (k.ray >= dm.b * dm.v * R) return false;
+  k.featS = smem + (size_t)wv * wave_lds_floats(k.T, dm.c, k.P);
+  k.peS = k.featS + (size_t)k.T * k.cs;
+  k.tokS = k.peS + (size_t)k.T * k.Ps;
+  k.rdS = k.tokS + (size_t)k.T * 8;
+  k.r = k.ray % R;
+  k.bv = (size_t)(k.ray / R);
+  k.v = (int)(k.bv % dm.v);
+  k.bbase = k.bv - k.v;
+  return true;
+}
+
+template <int LPT>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
                              const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -140,115 +392,50 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
                              float scale, float* __restrict__ fbar, float* __restrict__ pbar,
                              float* __restrict__ abar, float* __restrict__ attn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, P = 2 * dm.octaves, H = dm.heads;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t ray = (size_t)blockIdx.x * kAttnWaves + wv;      // (b v r)
-  if (ray >= (size_t)dm.b * dm.v * R) return;
-  float* featS = smem + (size_t)wv * (T * dm.c + T * P + kMaxHeads * T);
-  float* peS = featS + T * dm.c;
-  float* scS = peS + T * P;
-  const int r = (int)(ray % R);
-  const size_t bv = ray / R;
-  const int v = (int)(bv % dm.v);
-  const size_t bbase = bv - v;
-  const int c0 = lane * CPL;
-  const bool lane_c = c0 < dm.c;
+  RayCtx k;
+  if (!ray_setup(dm, smem, k)) return;
+  const int lane = threadIdx.x & 63;
+  stage_tokens<LPT>(dm, k, lane, fmap, xy, flags, rd);
 
-  float q[kMaxHeads][CPL], uu[kMaxHeads];
+  const size_t rh = (size_t)k.ray * k.H;
+  float sc[2][kMaxHeads];
+  token_scores(dm, k, lane, qt + rh * dm.c, u + rh * k.P, e ? e + rh * k.ovn : nullptr, sc);
+  // E: softmax over the T tokens
+  float mx[kMaxHeads];
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
-    uu[hh] = (hh < H && lane < P) ? u[(ray * H + hh) * P + lane] : 0.f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i)
-      q[hh][i] = (hh < H && lane_c) ? qt[(ray * H + hh) * dm.c + c0 + i] : 0.f;
+    sc[0][hh] = lane < k.T ? sc[0][hh] * scale : -__builtin_inff();
+    sc[1][hh] = lane + kWave < k.T ? sc[1][hh] * scale : -__builtin_inff();
+    mx[hh] = fmaxf(sc[0][hh], sc[1][hh]);
   }
-
-  // pass 1: gather every token once, scores for all heads
-  for (int t = 0; t < T; ++t) {
-    const int si = t / ovn, ov = t % ovn;
-    const size_t ro = (bv * ovn + ov) * R + r;
-    const size_t so = ro * dm.s + si;
-    const int src = (int)bbase + (ov < v ? ov : ov + 1);
-    const bool ok = flags[ro] & 1;
-    float f[CPL];
-    gather<CPL>(fmap + (size_t)src * R * dm.c, dm.h, dm.w, dm.c, c0, lane_c && ok,
-                corner_of(xy[2 * so], xy[2 * so + 1], dm.w, dm.h), f);
-    const float pe = lane < P ? pe_value(rd[so], lane) : 0.f;
-    float part[kMaxHeads];
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) {
-      float a = uu[hh] * pe;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) a = fmaf(q[hh][i], f[i], a);
-      if (e != nullptr && lane == 0 && hh < H) a += e[(ray * H + hh) * ovn + ov];
-      part[hh] = a;
-    }
-    wave_sum4_to_lane63(part[0], part[1], part[2], part[3]);
-    if (lane == 63) {
-#pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh) scS[hh * T + t] = part[hh] * scale;
-    }
-    if (lane_c) {
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) featS[t * dm.c + c0 + i] = f[i];
-    }
-    if (lane < P) peS[t * P + lane] = pe;
-  }
-  wave_lds_sync();
-
-  // softmax over the T tokens (lanes <-> tokens, T <= 128)
-  for (int hh = 0; hh < H; ++hh) {
-    const float s0 = lane < T ? scS[hh * T + lane] : -__builtin_inff();
-    const float s1 = lane + 64 < T ? scS[hh * T + lane + 64] : -__builtin_inff();
-    const float mx = wave_max_all(fmaxf(s0, s1));
-    const float e0 = lane < T ? __expf(s0 - mx) : 0.f;
-    const float e1 = lane + 64 < T ? __expf(s1 - mx) : 0.f;
-    const float inv = 1.0f / wave_sum_all(e0 + e1);
-    if (lane < T) { scS[hh * T + lane] = e0 * inv; attn[(ray * H + hh) * T + lane] = e0 * inv; }
-    if (lane + 64 < T) {
-      scS[hh * T + lane + 64] = e1 * inv; attn[(ray * H + hh) * T + lane + 64] = e1 * inv;
-    }
-  }
-  wave_lds_sync();
-
-  // pass 2: context
-  float acc[kMaxHeads][CPL], pacc[kMaxHeads], aacc[kMaxHeads];
+  wave_max4_to_lane63(mx[0], mx[1], mx[2], mx[3]);
+  float sm[kMaxHeads];
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
-    pacc[hh] = 0.f; aacc[hh] = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) acc[hh][i] = 0.f;
+    const float m = lane_bcast(mx[hh], 63);
+    sc[0][hh] = lane < k.T ? __expf(sc[0][hh] - m) : 0.f;
+    sc[1][hh] = lane + kWave < k.T ? __expf(sc[1][hh] - m) : 0.f;
+    sm[hh] = sc[0][hh] + sc[1][hh];
   }
-  for (int t = 0; t < T; ++t) {
-    float f[CPL];
+  wave_sum4_to_lane63(sm[0], sm[1], sm[2], sm[3]);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) f[i] = lane_c ? featS[t * dm.c + c0 + i] : 0.f;
-    const float pe = lane < P ? peS[t * P + lane] : 0.f;
-    const bool mine = (t % ovn) == lane;     // lanes < ovn collect the per-view attention mass
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) {
-      const float a = hh < H ? scS[hh * T + t] : 0.f;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) acc[hh][i] = fmaf(a, f[i], acc[hh][i]);
-      pacc[hh] = fmaf(a, pe, pacc[hh]);
-      aacc[hh] += mine ? a : 0.f;
+  for (int hh = 0; hh < kMaxHeads; ++hh) {
+    const float inv = 1.0f / lane_bcast(sm[hh], 63);
+    sc[0][hh] *= inv; sc[1][hh] *= inv;
+    if (hh < k.H) {
+      if (lane < k.T) attn[(rh + hh) * k.T + lane] = sc[0][hh];
+      if (lane + kWave < k.T) attn[(rh + hh) * k.T + lane + kWave] = sc[1][hh];
     }
   }
-  for (int hh = 0; hh < H; ++hh) {
-    if (lane_c) {
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) fbar[(ray * H + hh) * dm.c + c0 + i] = acc[hh][i];
-    }
-    if (lane < P) pbar[(ray * H + hh) * P + lane] = pacc[hh];
-    if (lane < ovn) abar[(ray * H + hh) * ovn + lane] = aacc[hh];
-  }
+  weighted_context<LPT>(dm, k, lane, sc, fbar + rh * dm.c, pbar + rh * k.P,
+                        e ? abar + rh * k.ovn : nullptr);
 }
 
 // ------------------------------------------------------------------------------------
 // attention backward, per ray: dq~, du, de and the per-token coefficients the feature-map
 // scatter needs (ds = scale * a (da - sum a da))
 // ------------------------------------------------------------------------------------
-template <int CPL>
+template <int LPT>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
                               const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -258,182 +445,226 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
                               float* __restrict__ dqt, float* __restrict__ du,
                               float* __restrict__ de, float* __restrict__ ds_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, P = 2 * dm.octaves, H = dm.heads;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t ray = (size_t)blockIdx.x * kAttnWaves + wv;
-  if (ray >= (size_t)dm.b * dm.v * R) return;
-  float* featS = smem + (size_t)wv * (T * dm.c + T * P + kMaxHeads * T);
-  float* peS = featS + T * dm.c;
-  float* daS = peS + T * P;
-  const int r = (int)(ray % R);
-  const size_t bv = ray / R;
-  const int v = (int)(bv % dm.v);
-  const size_t bbase = bv - v;
-  const int c0 = lane * CPL;
-  const bool lane_c = c0 < dm.c;
+  RayCtx k;
+  if (!ray_setup(dm, smem, k)) return;
+  const int lane = threadIdx.x & 63;
+  stage_tokens<LPT>(dm, k, lane, fmap, xy, flags, rd);
 
-  float g[kMaxHeads][CPL], gp[kMaxHeads];
-#pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
-    gp[hh] = (hh < H && lane < P) ? dpbar[(ray * H + hh) * P + lane] : 0.f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i)
-      g[hh][i] = (hh < H && lane_c) ? dfbar[(ray * H + hh) * dm.c + c0 + i] : 0.f;
-  }
+  const size_t rh = (size_t)k.ray * k.H;
   // da_{h,t} = dfbar_h . feat_t + dpbar_h . pe_t + dabar_{h,ov(t)}
-  for (int t = 0; t < T; ++t) {
-    const int si = t / ovn, ov = t % ovn;
-    const size_t ro = (bv * ovn + ov) * R + r;
-    const size_t so = ro * dm.s + si;
-    const int src = (int)bbase + (ov < v ? ov : ov + 1);
-    const bool ok = flags[ro] & 1;
-    float f[CPL];
-    gather<CPL>(fmap + (size_t)src * R * dm.c, dm.h, dm.w, dm.c, c0, lane_c && ok,
-                corner_of(xy[2 * so], xy[2 * so + 1], dm.w, dm.h), f);
-    const float pe = lane < P ? pe_value(rd[so], lane) : 0.f;
-    float part[kMaxHeads];
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) {
-      float a = gp[hh] * pe;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) a = fmaf(g[hh][i], f[i], a);
-      if (lane == 0 && hh < H) a += dabar[(ray * H + hh) * ovn + ov];
-      part[hh] = a;
-    }
-    wave_sum4_to_lane63(part[0], part[1], part[2], part[3]);
-    if (lane == 63) {
-#pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh) daS[hh * T + t] = part[hh];
-    }
-    if (lane_c) {
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) featS[t * dm.c + c0 + i] = f[i];
-    }
-    if (lane < P) peS[t * P + lane] = pe;
-  }
-  wave_lds_sync();
-  // softmax backward: ds = scale * a * (da - sum_t a da)
-  for (int hh = 0; hh < H; ++hh) {
-    const float a0 = lane < T ? attn[(ray * H + hh) * T + lane] : 0.f;
-    const float a1 = lane + 64 < T ? attn[(ray * H + hh) * T + lane + 64] : 0.f;
-    const float d0 = lane < T ? daS[hh * T + lane] : 0.f;
-    const float d1 = lane + 64 < T ? daS[hh * T + lane + 64] : 0.f;
-    const float dot = wave_sum_all(a0 * d0 + a1 * d1);
-    if (lane < T) {
-      const float dsv = scale * a0 * (d0 - dot);
-      daS[hh * T + lane] = dsv; ds_out[(ray * H + hh) * T + lane] = dsv;
-    }
-    if (lane + 64 < T) {
-      const float dsv = scale * a1 * (d1 - dot);
-      daS[hh * T + lane + 64] = dsv; ds_out[(ray * H + hh) * T + lane + 64] = dsv;
-    }
-  }
-  wave_lds_sync();
-  float acc[kMaxHeads][CPL], pacc[kMaxHeads], eacc[kMaxHeads];
+  float da[2][kMaxHeads];
+  token_scores(dm, k, lane, dfbar + rh * dm.c, dpbar + rh * k.P,
+               dabar ? dabar + rh * k.ovn : nullptr, da);
+  float a[2][kMaxHeads], dot[kMaxHeads];
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
-    pacc[hh] = 0.f; eacc[hh] = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) acc[hh][i] = 0.f;
+    a[0][hh] = (hh < k.H && lane < k.T) ? attn[(rh + hh) * k.T + lane] : 0.f;
+    a[1][hh] = (hh < k.H && lane + kWave < k.T) ? attn[(rh + hh) * k.T + lane + kWave] : 0.f;
+    dot[hh] = fmaf(a[0][hh], da[0][hh], a[1][hh] * da[1][hh]);
   }
-  for (int t = 0; t < T; ++t) {
-    float f[CPL];
+  wave_sum4_to_lane63(dot[0], dot[1], dot[2], dot[3]);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) f[i] = lane_c ? featS[t * dm.c + c0 + i] : 0.f;
-    const float pe = lane < P ? peS[t * P + lane] : 0.f;
-    const bool mine = (t % ovn) == lane;
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) {
-      const float dsv = hh < H ? daS[hh * T + t] : 0.f;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) acc[hh][i] = fmaf(dsv, f[i], acc[hh][i]);
-      pacc[hh] = fmaf(dsv, pe, pacc[hh]);
-      eacc[hh] += mine ? dsv : 0.f;
+  for (int hh = 0; hh < kMaxHeads; ++hh) {
+    const float d = lane_bcast(dot[hh], 63);
+    da[0][hh] = scale * a[0][hh] * (da[0][hh] - d);
+    da[1][hh] = scale * a[1][hh] * (da[1][hh] - d);
+    if (hh < k.H) {
+      if (lane < k.T) ds_out[(rh + hh) * k.T + lane] = da[0][hh];
+      if (lane + kWave < k.T) ds_out[(rh + hh) * k.T + lane + kWave] = da[1][hh];
     }
   }
-  for (int hh = 0; hh < H; ++hh) {
-    if (lane_c) {
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) dqt[(ray * H + hh) * dm.c + c0 + i] = acc[hh][i];
-    }
-    if (lane < P) du[(ray * H + hh) * P + lane] = pacc[hh];
-    if (lane < ovn) de[(ray * H + hh) * ovn + lane] = eacc[hh];
-  }
+  weighted_context<LPT>(dm, k, lane, da, dqt + rh * dm.c, du + rh * k.P, de + rh * k.ovn);
 }
 
 // ------------------------------------------------------------------------------------
 // feature-map gradient: dF[src][y][x][c] += w_corner * sum_h (a dfbar_h[c] + ds q~_h[c])
-// One block owns (source image, slice of CS channels) and keeps that slice of the WHOLE
-// gradient image in LDS (h*w*CS floats, up to 128 KB of the CU's 160 KB): every token of
-// every ray that samples this image is splatted with LDS float atomics, then the slice is
-// written out once -- no global atomics (grid_sample's backward issues ~1e9 of them).
+//
+// grid_sample's backward is a scatter of (rays x tokens x 4 corners x c) float atomics
+// (~1e9 per layer at the paper config).  Measured on MI355X, neither flavour of float atomic
+// is usable at that count: global atomics reach 21-161 G/s, and a wave-level LDS
+// ds_add_f32 takes ~193 clocks whatever the address pattern (0.33 lanes/clk per CU,
+// tools/lds_atomic_microbench.hip) against ~10 clocks for a plain ds_read/add/ds_write.
+// So the scatter is turned into an owner-computes pass with NO atomics:
+//   * one wave owns a TS x TS pixel tile of one source image, all channels, in LDS
+//     ((TS*TS + 4) * c floats); lanes <-> channels, so one LDS read-modify-write touches 64
+//     distinct addresses and a wave is the only writer of its tile;
+//   * the wave culls the rays of the casting views against its tile with a packed pixel
+//     bounding box of each ray's samples (64 rays per test, one ballot), then, for a hit,
+//     computes the corner records of the ray's samples lanes <-> samples and walks only the
+//     samples that really touch the tile (second ballot);
+//   * corners outside the tile/image are redirected to four dummy pixels with weight 0, so
+//     the four read-modify-writes of a sample are branch free and independent.
+// The summation order is fixed (view, ray, sample, corner): the gradient is bit-reproducible,
+// which atomics never were.  Every pixel is written exactly once; dfmap needs no memset.
 // ------------------------------------------------------------------------------------
-template <int CS>
 __global__ void __launch_bounds__(256)
+epipolar_ray_box_kernel(AttnDims dm, const float* __restrict__ xy,
+                        const uint8_t* __restrict__ flags, uint32_t* __restrict__ boxes) {
+  const size_t n = (size_t)dm.b * dm.v * (dm.v - 1) * dm.h * dm.w;
+  const size_t ro = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ro >= n) return;
+  uint32_t box = 0x00FF00FFu;                       // empty: min 255 > max 0
+  if (flags[ro] & 1) {
+    const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s));
+    const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s + dm.s - 1));
+    const Corner a = corner_of(p0.x, p0.y, dm.w, dm.h), c = corner_of(p1.x, p1.y, dm.w, dm.h);
+    // the samples lie on the segment between the first and the last one; one pixel of slack
+    // for the rounding of the interpolation, then the +1 corner
+    const int x0 = max(min(a.x0, c.x0) - 1, 0), x1 = min(max(a.x0, c.x0) + 2, dm.w - 1);
+    const int y0 = max(min(a.y0, c.y0) - 1, 0), y1 = min(max(a.y0, c.y0) + 2, dm.h - 1);
+    if (x0 <= x1 && y0 <= y1)
+      box = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24);
+  }
+  boxes[ro] = box;
+}
+
+template <int CPL> struct LaneVec;
+template <> struct LaneVec<1> { using type = float; };
+template <> struct LaneVec<2> { using type = float2; };
+template <> struct LaneVec<4> { using type = float4; };
+
+template <int CPL>
+__device__ __forceinline__ void load_cpl(const float* __restrict__ p, float* out) {
+  using V = typename LaneVec<CPL>::type;
+  const V q = *reinterpret_cast<const V*>(p);
+  const float* f = reinterpret_cast<const float*>(&q);
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) out[i] = f[i];
+}
+
+__device__ __forceinline__ int lane_bcast_i(int v, int lane) {
+  return __builtin_amdgcn_readlane(v, lane);
+}
+
+template <int CPL, int TS>
+__global__ void __launch_bounds__(kWave)
 epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
-                      const uint8_t* __restrict__ flags, const float* __restrict__ attn,
+                      const uint32_t* __restrict__ boxes, const float* __restrict__ attn,
                       const float* __restrict__ ds, const float* __restrict__ dfbar,
                       const float* __restrict__ qt, float* __restrict__ dfmap) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [h*w][CS]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TS*TS + 4)][c]
+  using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
-  const int n_slices = (dm.c + CS - 1) / CS;
-  const int slice = blockIdx.x % n_slices;
-  const int src_bv = blockIdx.x / n_slices;          // (b, source view)
+  const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
+  const int tile_id = blockIdx.x % (tiles_x * tiles_y);
+  const int src_bv = blockIdx.x / (tiles_x * tiles_y);          // (b, source view)
   const int b = src_bv / dm.v, sv = src_bv % dm.v;
-  const int cbase = slice * CS;
-  for (int i = threadIdx.x; i < R * CS; i += blockDim.x) tile[i] = 0.f;
-  __syncthreads();
-  // casting views v != sv; their ov index pointing at sv is ov = sv < v ? sv : sv - 1
-  const size_t pairs_per_view = (size_t)R * dm.s;
+  const int tx0 = (tile_id % tiles_x) * TS, ty0 = (tile_id / tiles_x) * TS;
+  const int tx1 = min(tx0 + TS, dm.w) - 1, ty1 = min(ty0 + TS, dm.h) - 1;
+  const int lane = threadIdx.x;
+  const int c0 = lane * CPL;
+  const bool lane_c = c0 < dm.c;
+  const int cl = lane_c ? c0 : 0;
+  for (int i = lane; i < (TS * TS + 4) * dm.c; i += kWave) tile[i] = 0.f;
+  wave_lds_sync();
+
   for (int v = 0; v < dm.v; ++v) {
     if (v == sv) continue;
     const int ov = sv < v ? sv : sv - 1;
     const size_t bv = (size_t)b * dm.v + v;
-    for (size_t pr = threadIdx.x; pr < pairs_per_view; pr += blockDim.x) {
-      const int r = (int)(pr / dm.s), si = (int)(pr % dm.s);
-      const size_t ro = (bv * ovn + ov) * R + r;
-      if (!(flags[ro] & 1)) continue;
-      const size_t so = ro * dm.s + si;
-      const size_t ray = bv * R + r;
-      const int t = si * ovn + ov;
-      float df[CS];
+    const size_t ro0 = (bv * ovn + ov) * R;
+    for (int r0 = 0; r0 < R; r0 += kWave) {
+      const int r = r0 + lane;
+      const uint32_t box = r < R ? boxes[ro0 + r] : 0x00FF00FFu;
+      const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
+      const bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+      uint64_t rays = __ballot(hit);
+      while (rays) {
+        const int j = __builtin_ctzll(rays);
+        rays &= rays - 1;
+        const int rr = r0 + j;                                   // uniform
+        const size_t ro = ro0 + rr;
+        const size_t ray = bv * R + rr;
+        for (int g0 = 0; g0 < dm.s; g0 += kWave) {               // one pass when s <= 64
+          // lanes <-> samples: corner records relative to this tile
+          const int si = g0 + lane;
+          const bool tok = si < dm.s;
+          const float2 p = tok ? *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s + si))
+                               : make_float2(-4.f, -4.f);
+          const Corner kq = corner_of(p.x, p.y, dm.w, dm.h);
+          int off[4]; float wt[4]; bool any = false;
 #pragma unroll
-      for (int k = 0; k < CS; ++k) df[k] = 0.f;
-      for (int hh = 0; hh < H; ++hh) {
-        const float a = attn[(ray * H + hh) * T + t], d = ds[(ray * H + hh) * T + t];
-        const float* gq = dfbar + (ray * H + hh) * dm.c + cbase;
-        const float* qq = qt + (ray * H + hh) * dm.c + cbase;
+          for (int cr = 0; cr < 4; ++cr) {
+            const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
+            const bool in = tok && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
+            const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
+            off[cr] = in ? (yy - ty0) * TS + (xx - tx0) : TS * TS + cr;
+            wt[cr] = in ? wx * wy : 0.f;
+            any |= in;
+          }
+          uint64_t toks = __ballot(any);
+          if (toks == 0) continue;                               // box hit, no sample inside
+          const int t = (tok ? si : 0) * ovn + ov;
+          float av[kMaxHeads], dv[kMaxHeads];
 #pragma unroll
-        for (int k = 0; k < CS; ++k)
-          if (cbase + k < dm.c) df[k] = fmaf(a, gq[k], fmaf(d, qq[k], df[k]));
-      }
-      const Corner kq = corner_of(xy[2 * so], xy[2 * so + 1], dm.w, dm.h);
-      const float wts[4] = {(1.f - kq.wx) * (1.f - kq.wy), kq.wx * (1.f - kq.wy),
-                            (1.f - kq.wx) * kq.wy, kq.wx * kq.wy};
+          for (int hh = 0; hh < kMaxHeads; ++hh) {
+            const size_t row = (ray * H + (hh < H ? hh : 0)) * T + t;
+            av[hh] = hh < H ? attn[row] : 0.f;
+            dv[hh] = hh < H ? ds[row] : 0.f;
+          }
+          // lanes <-> channels: this ray's rows
+          float gq[kMaxHeads][CPL], qq[kMaxHeads][CPL];
 #pragma unroll
-      for (int cr = 0; cr < 4; ++cr) {
-        const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
-        if (xx < 0 || xx >= dm.w || yy < 0 || yy >= dm.h) continue;
-        float* dst = tile + ((size_t)yy * dm.w + xx) * CS;
+          for (int hh = 0; hh < kMaxHeads; ++hh) {
+            const size_t row = (ray * H + (hh < H ? hh : 0)) * dm.c + cl;
+            load_cpl<CPL>(dfbar + row, gq[hh]);
+            load_cpl<CPL>(qt + row, qq[hh]);
+          }
+          while (toks) {
+            const int tl = __builtin_ctzll(toks);
+            toks &= toks - 1;
+            float df[CPL];
 #pragma unroll
-        for (int k = 0; k < CS; ++k) atomicAdd(dst + k, wts[cr] * df[k]);
+            for (int i = 0; i < CPL; ++i) df[i] = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < kMaxHeads; ++hh) {
+              const float a = lane_bcast(av[hh], tl), d = lane_bcast(dv[hh], tl);
+#pragma unroll
+              for (int i = 0; i < CPL; ++i) df[i] = fmaf(a, gq[hh][i], fmaf(d, qq[hh][i], df[i]));
+            }
+            // four distinct pixels (or distinct dummies): reads first, then the writes
+            V* dst[4]; V cur[4];
+#pragma unroll
+            for (int cr = 0; cr < 4; ++cr) {
+              dst[cr] = reinterpret_cast<V*>(tile + lane_bcast_i(off[cr], tl) * dm.c + cl);
+              cur[cr] = *dst[cr];
+            }
+#pragma unroll
+            for (int cr = 0; cr < 4; ++cr) {
+              const float wgt = lane_bcast(wt[cr], tl);
+              float* f = reinterpret_cast<float*>(&cur[cr]);
+#pragma unroll
+              for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[i], f[i]);
+              if (lane_c) *dst[cr] = cur[cr];
+            }
+          }
+        }
       }
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   float* out = dfmap + (size_t)src_bv * R * dm.c;
-  for (int i = threadIdx.x; i < R * CS; i += blockDim.x) {
-    const int pix = i / CS, k = i % CS;
-    if (cbase + k < dm.c) out[(size_t)pix * dm.c + cbase + k] = tile[i];
-  }
+  for (int py = ty0; py <= ty1; ++py)
+    for (int px = tx0; px <= tx1; ++px) {
+      if (!lane_c) continue;
+      const V val = *reinterpret_cast<const V*>(tile + ((py - ty0) * TS + (px - tx0)) * dm.c + c0);
+      *reinterpret_cast<V*>(out + ((size_t)py * dm.w + px) * dm.c + c0) = val;
+    }
 }
 
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 static size_t attn_smem(const AttnDims& dm) {
-  const int T = dm.s * (dm.v - 1), P = 2 * dm.octaves;
-  return (size_t)kAttnWaves * (T * dm.c + T * P + kMaxHeads * T) * sizeof(float);
+  return (size_t)kAttnWaves * wave_lds_floats(dm.s * (dm.v - 1), dm.c, 2 * dm.octaves) *
+         sizeof(float);
+}
+
+static bool attn_dims_ok(const AttnDims& dm) {
+  return attn_smem(dm) <= 160 * 1024 && dm.heads >= 1 && dm.heads <= kMaxHeads &&
+         dm.s * (dm.v - 1) <= 128 && dm.s * (dm.v - 1) >= 1 && 2 * dm.octaves <= 64 &&
+         dm.octaves >= 1 && dm.c % 4 == 0 && dm.c >= 4 && dm.c <= 256 &&
+         (size_t)dm.b * dm.v * dm.h * dm.w < (size_t)1 << 30;
 }
 
 int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* xy,
@@ -447,24 +678,32 @@ int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* x
   return PS_OK;
 }
 
+// lanes per token of the gather phase: c/4 rounded up to a power of two
+#define PS_BY_LPT(GO)                                  \
+  do {                                                 \
+    const int q = dm.c / 4;                            \
+    if (q <= 1) GO(1); else if (q <= 2) GO(2);         \
+    else if (q <= 4) GO(4); else if (q <= 8) GO(8);    \
+    else if (q <= 16) GO(16); else if (q <= 32) GO(32);\
+    else GO(64);                                       \
+  } while (0)
+
 int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const float* xy,
                                  const uint8_t* flags, const float* rd, const float* qt,
                                  const float* u, const float* e, float scale, float* fbar,
                                  float* pbar, float* abar, float* attn, hipStream_t st) {
+  if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
   const size_t sm = attn_smem(dm);
-  if (sm > 160 * 1024 || dm.heads > kMaxHeads || dm.s * (dm.v - 1) > 128 || 2 * dm.octaves > 64)
-    return PS_ERR_UNSUPPORTED;
-#define PS_GO(CPL)                                                                              \
+#define PS_GO(L)                                                                                \
   do {                                                                                          \
-    (void)hipFuncSetAttribute((const void*)epipolar_attn_forward_kernel<CPL>,                   \
+    (void)hipFuncSetAttribute((const void*)epipolar_attn_forward_kernel<L>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
-    hipLaunchKernelGGL(epipolar_attn_forward_kernel<CPL>, grid, block, sm, st, dm, fmap, xy,    \
+    hipLaunchKernelGGL(epipolar_attn_forward_kernel<L>, grid, block, sm, st, dm, fmap, xy,      \
                        flags, rd, qt, u, e, scale, fbar, pbar, abar, attn);                     \
   } while (0)
-  if (dm.c <= 64) PS_GO(1); else if (dm.c <= 128) PS_GO(2); else if (dm.c <= 256) PS_GO(4);
-  else return PS_ERR_UNSUPPORTED;
+  PS_BY_LPT(PS_GO);
 #undef PS_GO
   return PS_OK;
 }
@@ -473,39 +712,34 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                                   const uint8_t* flags, const float* rd, const float* qt,
                                   const float* attn, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
-                                  float* de, float* ds, float* dfmap, hipStream_t st) {
+                                  float* de, float* ds, float* dfmap, uint32_t* boxes,
+                                  hipStream_t st) {
+  if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
   const size_t sm = attn_smem(dm);
-  if (sm > 160 * 1024 || dm.heads > kMaxHeads || dm.s * (dm.v - 1) > 128 || 2 * dm.octaves > 64)
-    return PS_ERR_UNSUPPORTED;
-#define PS_GO(CPL)                                                                              \
+#define PS_GO(L)                                                                                \
   do {                                                                                          \
-    (void)hipFuncSetAttribute((const void*)epipolar_attn_backward_kernel<CPL>,                  \
+    (void)hipFuncSetAttribute((const void*)epipolar_attn_backward_kernel<L>,                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
-    hipLaunchKernelGGL(epipolar_attn_backward_kernel<CPL>, grid, block, sm, st, dm, fmap, xy,   \
+    hipLaunchKernelGGL(epipolar_attn_backward_kernel<L>, grid, block, sm, st, dm, fmap, xy,     \
                        flags, rd, attn, dfbar, dpbar, dabar, scale, dqt, du, de, ds);           \
   } while (0)
-  if (dm.c <= 64) PS_GO(1); else if (dm.c <= 128) PS_GO(2); else if (dm.c <= 256) PS_GO(4);
-  else return PS_ERR_UNSUPPORTED;
+  PS_BY_LPT(PS_GO);
 #undef PS_GO
   if (dfmap != nullptr) {
-    // channel slice so that h*w*CS floats fit in 128 KB of LDS
-    const size_t R = (size_t)dm.h * dm.w;
-    int cs = 8;
-    while (cs > 1 && R * cs * 4 > 128 * 1024) cs >>= 1;
-    if (R * cs * 4 > 160 * 1024) return PS_ERR_UNSUPPORTED;
-    const int n_slices = (dm.c + cs - 1) / cs;
-    dim3 g2((unsigned)(dm.b * dm.v * n_slices)), b2(256);
-    const size_t sm2 = R * cs * 4;
-#define PS_DF(CS)                                                                               \
-  do {                                                                                          \
-    (void)hipFuncSetAttribute((const void*)epipolar_dfmap_kernel<CS>,                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);            \
-    hipLaunchKernelGGL(epipolar_dfmap_kernel<CS>, g2, b2, sm2, st, dm, xy, flags, attn, ds,     \
-                       dfbar, qt, dfmap);                                                       \
-  } while (0)
-    if (cs == 8) PS_DF(8); else if (cs == 4) PS_DF(4); else if (cs == 2) PS_DF(2); else PS_DF(1);
+    if (boxes == nullptr || dm.w > 255 || dm.h > 255) return PS_ERR_BAD_ARG;
+    const size_t n_ro = rays * (dm.v - 1);
+    hipLaunchKernelGGL(epipolar_ray_box_kernel, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
+                       0, st, dm, xy, flags, boxes);
+    constexpr int TS = 4;
+    const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
+    dim3 g2((unsigned)(dm.b * dm.v * tiles)), b2(kWave);
+    const size_t sm2 = (size_t)(TS * TS + 4) * dm.c * sizeof(float);
+#define PS_DF(CPL)                                                                              \
+  hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, xy, boxes, attn,    \
+                     ds, dfbar, qt, dfmap)
+    if (dm.c <= 64) PS_DF(1); else if (dm.c <= 128) PS_DF(2); else PS_DF(4);
 #undef PS_DF
   }
   return PS_OK;

@@ -290,13 +290,14 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
                                    const float* rel_disparity, const float* qt,
                                    const float* attn, const float* dfbar, const float* dpbar,
                                    const float* dabar, float scale, float* dqt, float* du,
-                                   float* de, float* ds, float* dfmap, void* stream) {
+                                   float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
+                                   void* stream) {
   if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !dfbar ||
-      !dpbar || !dabar || !dqt || !du || !de || !ds)
+      !dpbar || !dabar || !dqt || !du || !de || !ds || (dfmap && !ray_boxes))
     return PS_ERR_BAD_ARG;
   if (int rc = launch_epipolar_attn_backward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
                                              qt, attn, dfbar, dpbar, dabar, scale, dqt, du, de,
-                                             ds, dfmap, (hipStream_t)stream))
+                                             ds, dfmap, ray_boxes, (hipStream_t)stream))
     return rc;
   return check_launch();
 }

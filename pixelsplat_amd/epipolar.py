@@ -124,11 +124,15 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         du = torch.empty((R, heads, P), **f32)
         de = torch.empty((R, heads, ov), **f32)
         ds = torch.empty((R, heads, T), **f32)
-        dfmap = torch.empty_like(fmap) if ctx.needs_input_grad[2] else None
+        dfmap = boxes = None
+        if ctx.needs_input_grad[2]:
+            dfmap = torch.empty_like(fmap)
+            boxes = torch.empty((R * ov,), dtype=torch.int32, device=fmap.device)
         _lib.check(lib.ps_epipolar_attention_backward(
             C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), _p(qt), _p(attn),
             _p(dfbar.contiguous()), _p(dpbar.contiguous()), _p(dabar.contiguous()),
-            C.c_float(ctx.scale), _p(dqt), _p(du), _p(de), _p(ds), _p(dfmap), _stream()),
+            C.c_float(ctx.scale), _p(dqt), _p(du), _p(de), _p(ds), _p(dfmap), _p(boxes),
+            _stream()),
             "ps_epipolar_attention_backward")
         return (None, None, dfmap, None, None, None, dqt, du, de if ctx.has_e else None)
 
