@@ -536,13 +536,16 @@ __device__ __forceinline__ int lane_bcast_i(int v, int lane) {
   return __builtin_amdgcn_readlane(v, lane);
 }
 
+constexpr int kDfWaves = 4;   // waves per tile, each with a private copy (rays interleaved)
+constexpr int kDfChunk = 4096; // rays culled per pass (bounds the per-wave hit list)
+
 template <int CPL, int TS>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kDfWaves* kWave)
 epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
                       const uint32_t* __restrict__ boxes, const float* __restrict__ attn,
                       const float* __restrict__ ds, const float* __restrict__ dfbar,
                       const float* __restrict__ qt, float* __restrict__ dfmap) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TS*TS + 4)][c]
+  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][(TS*TS + 4)][c]
   using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
   const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
@@ -551,65 +554,82 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
   const int b = src_bv / dm.v, sv = src_bv % dm.v;
   const int tx0 = (tile_id % tiles_x) * TS, ty0 = (tile_id / tiles_x) * TS;
   const int tx1 = min(tx0 + TS, dm.w) - 1, ty1 = min(ty0 + TS, dm.h) - 1;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c0 = lane * CPL;
   const bool lane_c = c0 < dm.c;
   const int cl = lane_c ? c0 : 0;
+  float* tile = tiles + (size_t)wv * (TS * TS + 4) * dm.c;
   for (int i = lane; i < (TS * TS + 4) * dm.c; i += kWave) tile[i] = 0.f;
   wave_lds_sync();
+
+  // per-wave list of the rays whose box overlaps the tile (uint16 ray index inside the
+  // current super-chunk of kDfChunk rays), behind the tile copies
+  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * (TS * TS + 4) * dm.c) +
+                   (size_t)wv * (kDfChunk / kDfWaves);
+  const int ngroups = (dm.s + kWave - 1) / kWave;                // 1 when s <= 64
+
+  struct RayRegs {
+    float2 p;
+    float av[kMaxHeads], dv[kMaxHeads];
+    float gq[kMaxHeads][CPL], qq[kMaxHeads][CPL];
+  };
 
   for (int v = 0; v < dm.v; ++v) {
     if (v == sv) continue;
     const int ov = sv < v ? sv : sv - 1;
     const size_t bv = (size_t)b * dm.v + v;
     const size_t ro0 = (bv * ovn + ov) * R;
-    for (int r0 = 0; r0 < R; r0 += kWave) {
-      const int r = r0 + lane;
-      const uint32_t box = r < R ? boxes[ro0 + r] : 0x00FF00FFu;
-      const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
-      const bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
-      uint64_t rays = __ballot(hit);
-      while (rays) {
-        const int j = __builtin_ctzll(rays);
-        rays &= rays - 1;
-        const int rr = r0 + j;                                   // uniform
-        const size_t ro = ro0 + rr;
+    for (int chunk0 = 0; chunk0 < R; chunk0 += kDfChunk) {
+      // 1. cull: lanes <-> rays, matched rays appended to the wave's list
+      int count = 0;
+      for (int r0 = chunk0 + wv * kWave; r0 < min(chunk0 + kDfChunk, R); r0 += kDfWaves * kWave) {
+        const int r = r0 + lane;
+        const uint32_t box = r < R ? boxes[ro0 + r] : 0x00FF00FFu;
+        const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
+        const bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+        const uint64_t m = __ballot(hit);
+        if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)(r - chunk0);
+        count += __popcll(m);
+      }
+      wave_lds_sync();
+      if (count == 0) continue;
+      // 2. walk the list; the loads of item i+1 are in flight while item i is processed
+      //    (a matched ray costs two dependent global-load latencies otherwise)
+      auto fetch = [&](int item, RayRegs& x) {
+        const int rr = chunk0 + list[item / ngroups];
+        const int si = min((item % ngroups) * kWave + lane, dm.s - 1);
         const size_t ray = bv * R + rr;
-        for (int g0 = 0; g0 < dm.s; g0 += kWave) {               // one pass when s <= 64
-          // lanes <-> samples: corner records relative to this tile
-          const int si = g0 + lane;
-          const bool tok = si < dm.s;
-          const float2 p = tok ? *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s + si))
-                               : make_float2(-4.f, -4.f);
-          const Corner kq = corner_of(p.x, p.y, dm.w, dm.h);
-          int off[4]; float wt[4]; bool any = false;
+        x.p = *reinterpret_cast<const float2*>(xy + 2 * ((ro0 + rr) * dm.s + si));
 #pragma unroll
-          for (int cr = 0; cr < 4; ++cr) {
-            const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
-            const bool in = tok && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
-            const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
-            off[cr] = in ? (yy - ty0) * TS + (xx - tx0) : TS * TS + cr;
-            wt[cr] = in ? wx * wy : 0.f;
-            any |= in;
-          }
-          uint64_t toks = __ballot(any);
-          if (toks == 0) continue;                               // box hit, no sample inside
-          const int t = (tok ? si : 0) * ovn + ov;
-          float av[kMaxHeads], dv[kMaxHeads];
+        for (int hh = 0; hh < kMaxHeads; ++hh) {
+          const size_t rowh = ray * H + (hh < H ? hh : 0);
+          x.av[hh] = attn[rowh * T + si * ovn + ov];
+          x.dv[hh] = ds[rowh * T + si * ovn + ov];
+          load_cpl<CPL>(dfbar + rowh * dm.c + cl, x.gq[hh]);
+          load_cpl<CPL>(qt + rowh * dm.c + cl, x.qq[hh]);
+        }
+      };
+      const int n_items = count * ngroups;
+      RayRegs cur;
+      fetch(0, cur);
+      for (int item = 0; item < n_items; ++item) {
+        RayRegs nxt;
+        fetch(min(item + 1, n_items - 1), nxt);
+        // lanes <-> samples: corner records relative to this tile
+        const bool tok = (item % ngroups) * kWave + lane < dm.s;
+        const Corner kq = corner_of(cur.p.x, cur.p.y, dm.w, dm.h);
+        int off[4]; float wt[4]; bool any = false;
 #pragma unroll
-          for (int hh = 0; hh < kMaxHeads; ++hh) {
-            const size_t row = (ray * H + (hh < H ? hh : 0)) * T + t;
-            av[hh] = hh < H ? attn[row] : 0.f;
-            dv[hh] = hh < H ? ds[row] : 0.f;
-          }
-          // lanes <-> channels: this ray's rows
-          float gq[kMaxHeads][CPL], qq[kMaxHeads][CPL];
-#pragma unroll
-          for (int hh = 0; hh < kMaxHeads; ++hh) {
-            const size_t row = (ray * H + (hh < H ? hh : 0)) * dm.c + cl;
-            load_cpl<CPL>(dfbar + row, gq[hh]);
-            load_cpl<CPL>(qt + row, qq[hh]);
-          }
+        for (int cr = 0; cr < 4; ++cr) {
+          const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
+          const bool in = tok && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
+          const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
+          off[cr] = (in ? (yy - ty0) * TS + (xx - tx0) : TS * TS + cr) * dm.c;
+          wt[cr] = in ? wx * wy : 0.f;
+          any |= in;
+        }
+        uint64_t toks = __ballot(any);
+        if (lane_c) {                        // readlane ignores EXEC; idle channel lanes sit out
           while (toks) {
             const int tl = __builtin_ctzll(toks);
             toks &= toks - 1;
@@ -618,38 +638,48 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
             for (int i = 0; i < CPL; ++i) df[i] = 0.f;
 #pragma unroll
             for (int hh = 0; hh < kMaxHeads; ++hh) {
-              const float a = lane_bcast(av[hh], tl), d = lane_bcast(dv[hh], tl);
+              if (hh < H) {
+                const float a = lane_bcast(cur.av[hh], tl), d = lane_bcast(cur.dv[hh], tl);
 #pragma unroll
-              for (int i = 0; i < CPL; ++i) df[i] = fmaf(a, gq[hh][i], fmaf(d, qq[hh][i], df[i]));
+                for (int i = 0; i < CPL; ++i)
+                  df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
+              }
             }
             // four distinct pixels (or distinct dummies): reads first, then the writes
-            V* dst[4]; V cur[4];
+            V* dst[4]; V val[4];
 #pragma unroll
             for (int cr = 0; cr < 4; ++cr) {
-              dst[cr] = reinterpret_cast<V*>(tile + lane_bcast_i(off[cr], tl) * dm.c + cl);
-              cur[cr] = *dst[cr];
+              dst[cr] = reinterpret_cast<V*>(tile + lane_bcast_i(off[cr], tl) + c0);
+              val[cr] = *dst[cr];
             }
 #pragma unroll
             for (int cr = 0; cr < 4; ++cr) {
               const float wgt = lane_bcast(wt[cr], tl);
-              float* f = reinterpret_cast<float*>(&cur[cr]);
+              float* f = reinterpret_cast<float*>(&val[cr]);
 #pragma unroll
               for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[i], f[i]);
-              if (lane_c) *dst[cr] = cur[cr];
+              *dst[cr] = val[cr];
             }
           }
         }
+        cur = nxt;
       }
+      wave_lds_sync();
     }
   }
-  wave_lds_sync();
+  __syncthreads();
+  // fixed-order sum of the private copies, coalesced rows out
   float* out = dfmap + (size_t)src_bv * R * dm.c;
-  for (int py = ty0; py <= ty1; ++py)
-    for (int px = tx0; px <= tx1; ++px) {
-      if (!lane_c) continue;
-      const V val = *reinterpret_cast<const V*>(tile + ((py - ty0) * TS + (px - tx0)) * dm.c + c0);
-      *reinterpret_cast<V*>(out + ((size_t)py * dm.w + px) * dm.c + c0) = val;
-    }
+  const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+  for (int i = threadIdx.x; i < tw * th * dm.c; i += kDfWaves * kWave) {
+    const int pix = i / dm.c, ch = i - pix * dm.c;
+    const int py = pix / tw, px = pix - py * tw;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDfWaves; ++k)
+      acc += tiles[((size_t)k * (TS * TS + 4) + py * TS + px) * dm.c + ch];
+    out[((size_t)(ty0 + py) * dm.w + tx0 + px) * dm.c + ch] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -734,8 +764,9 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                        0, st, dm, xy, flags, boxes);
     constexpr int TS = 4;
     const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
-    dim3 g2((unsigned)(dm.b * dm.v * tiles)), b2(kWave);
-    const size_t sm2 = (size_t)(TS * TS + 4) * dm.c * sizeof(float);
+    dim3 g2((unsigned)(dm.b * dm.v * tiles)), b2(kDfWaves * kWave);
+    const size_t sm2 = (size_t)kDfWaves * (TS * TS + 4) * dm.c * sizeof(float) +
+                       kDfChunk * sizeof(uint16_t);
 #define PS_DF(CPL)                                                                              \
   hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, xy, boxes, attn,    \
                      ds, dfbar, qt, dfmap)

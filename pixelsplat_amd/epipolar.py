@@ -151,24 +151,42 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     s = geo.xy_sample.shape[-2]
     inner = w_q.shape[0]
     dh = inner // heads
-    R = x.shape[0]
-    q = (x.reshape(R, -1) @ w_q.T).reshape(R, heads, dh)
+    R, d_in = x.shape[0], x.shape[-1]
+    d_out = w_out.shape[0]
+    P = depth_w.shape[1]
+    # Every linear map on either side of the kernel is folded into ONE weight matrix per side
+    # (tiny [H, c, d] products, differentiable, recomputed each call), so the per-ray work
+    # outside the kernel is a single GEMM in (x -> q~|u|e) and a single GEMM out
+    # (fbar|pbar|abar -> y):  q~_h = (W_k,h^T W_q,h) x,  u_h = W_d^T q~_h,  e_h = E q~_h,
+    # y = sum_h (W_o,h W_v,h)(fbar_h + W_d pbar_h + E^T abar_h + b_d) + b_o.
     w_k = w_kv[:inner].reshape(heads, dh, c)
     w_v = w_kv[inner:].reshape(heads, dh, c)
-    qt = torch.einsum("rhd,hdc->rhc", q, w_k)                    # q~_h = W_k,h^T q_h
-    u = qt @ depth_w                                             # [R, H, P]
-    e = None if view_emb is None else qt @ view_emb.T            # [R, H, ov]
+    m_q = torch.einsum("hkc,hkd->hcd", w_k, w_q.reshape(heads, dh, d_in))       # [H, c, d]
+    n_o = torch.einsum("ohk,hkc->ohc", w_out.reshape(d_out, heads, dh), w_v)    # [o, H, c]
+    w_in = [m_q.reshape(heads * c, d_in),
+            torch.einsum("cp,hcd->hpd", depth_w, m_q).reshape(heads * P, d_in)]
+    w_o = [n_o.reshape(d_out, heads * c),
+           torch.einsum("ohc,cp->ohp", n_o, depth_w).reshape(d_out, heads * P)]
+    if view_emb is not None:
+        ovn = view_emb.shape[0]
+        w_in.append(torch.einsum("oc,hcd->hod", view_emb, m_q).reshape(heads * ovn, d_in))
+        w_o.append(torch.einsum("ohc,vc->ohv", n_o, view_emb).reshape(d_out, heads * ovn))
+    bias = n_o.sum(1) @ depth_b          # softmax weights sum to one
+    if b_out is not None:
+        bias = bias + b_out
+    x2 = x.reshape(R, d_in)
+    qt = (x2 @ w_in[0].T).reshape(R, heads, c)
+    u = (x2 @ w_in[1].T).reshape(R, heads, P)
+    e = None if view_emb is None else (x2 @ w_in[2].T).reshape(R, heads, -1)
     dims = (b, v, h, w, s, c, heads, octaves)
     fbar, pbar, abar, attn = _FusedEpipolarAttention.apply(
         dims, float(dh) ** -0.5, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample, geo.flags,
         geo.rel_disparity, qt, u, e)
-    ctxv = fbar + pbar @ depth_w.T + depth_b                     # sum_i a_i kv_i
+    out = torch.addmm(bias, fbar.reshape(R, heads * c), w_o[0].T)
+    out = torch.addmm(out, pbar.reshape(R, heads * P), w_o[1].T)
     if view_emb is not None:
-        ctxv = ctxv + abar @ view_emb
-    out = torch.einsum("rhc,hdc->rhd", ctxv, w_v).reshape(R, 1, inner)
-    out = out @ w_out.T
-    if b_out is not None:
-        out = out + b_out
+        out = torch.addmm(out, abar.reshape(R, -1), w_o[2].T)
+    out = out.reshape(R, 1, d_out)
     if return_attn:
         return out, attn.reshape(R, heads, 1, -1)
     return out
