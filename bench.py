@@ -3,11 +3,16 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py
-One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
-BASELINE.json configs[1] -- re10k 2-view, 256x256, batch 7 per GPU -> 7 scenes x 393 216
-Gaussians, 28 target views: batched HIP rasterizer forward, MSE loss, backward to
-dL/d{means, covariances, harmonics, opacities}.  Weak scaling: every rank renders its own
-batch (independent scenes; the path has no data-path collective -- DESIGN.md section (e)).
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM,
+BASELINE.json configs[1] -- re10k 2-view, 256x256, batch 7 per GPU:
+  (A) epipolar sampler + the two epipolar cross-attention layers of the encoder on the
+      [7, 2, 128, 64, 64] feature maps (geometry kernel, fused gather/attention kernels,
+      the folded weight GEMMs), forward and backward to features and weights;
+  (B) 7 scenes x 393 216 Gaussians -> 28 target views: batched HIP rasterizer forward, MSE
+      loss, backward to dL/d{means, covariances, harmonics, opacities}.
+value = 28 views / time of (A)+(B); (B) alone and (A) alone are timed after the contract's
+timed region and reported next to it.  Weak scaling: every rank processes its own batch
+(independent scenes; no data-path collective -- DESIGN.md section (e)).
 
 Prints ONE JSON line on rank 0.
 """
@@ -54,7 +59,7 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     R.parallel_backward(True)
     cores = os.cpu_count() or 1
     t_total = 0.0
-    linf, mse = 0.0, []
+    linf, mse, n_over, n_pix = 0.0, [], 0, 0
     vps = tgt.near.shape[1]
     for v in range(n_views):
         inp = oracle_view_inputs(gaussians, tgt, v // vps, v % vps, view_params=vps_np[v])
@@ -63,7 +68,10 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
         R.backward(st, dL[v])
         t_total += time.perf_counter() - t0
         diff = np.clip(gpu_images[v], 0, 1) - np.clip(st.image, 0, 1)
-        linf = max(linf, float(np.abs(gpu_images[v] - st.image).max()))
+        err = np.abs(gpu_images[v] - st.image)
+        linf = max(linf, float(err.max()))
+        n_over += int((err > 1e-4).sum())
+        n_pix += err.size
         mse.append(float((diff ** 2).mean()))
     R.parallel_backward(False)
     m = float(np.mean(mse))
@@ -72,7 +80,41 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
                 sample=f"first {n_views} of {tgt.near.numel()} views of the step (scene-major), "
                        f"{hw[0]}x{hw[1]}, G={gaussians.means.shape[1]}, fwd+bwd, "
                        f"oracle/raster_ref.c with OpenMP on {cores} threads, {t_total:.1f} s"), \
-        dict(linf=linf, psnr_db=psnr if psnr != float("inf") else 999.0)
+        dict(linf=linf, psnr_db=psnr if psnr != float("inf") else 999.0,
+             values_compared=n_pix, values_over_1e_4=n_over,
+             note="values over 1e-4 are alpha >= 1/255 / T < 1e-4 threshold flips (fp32 exp "
+                  "rounding differs between v_exp_f32 and libm); each is bounded by one "
+                  "minimum-alpha contribution, ~4e-3")
+
+
+def cpu_baseline_epipolar(et, feat_nhwc, ctx, num_samples, heads):
+    """Path (A) on the host: the oracle's unfused restatement (materialised kv, to_kv on every
+    token -- what the reference computes) for ONE scene of the batch, forward + backward
+    through torch autograd on the CPU.  Returns seconds per scene."""
+    from oracle import epipolar_ref as E
+
+    f = feat_nhwc[:1].detach().cpu().permute(0, 1, 4, 2, 3).contiguous().requires_grad_(True)
+    ext, intr = ctx.extrinsics[:1], ctx.intrinsics[:1]
+    near, far = ctx.near[:1], ctx.far[:1]
+    b, v, c, h, w = f.shape
+    par = {k: t.detach().cpu().requires_grad_(True) for k, t in et.state_dict().items()
+           if k.startswith(("transformer.layers", "depth_encoding")) and "self_attention" not in k}
+    t0 = time.perf_counter()
+    smp = E.sample(f, ext, intr, near, far, num_samples)
+    nf = (near[:, :, None, None, None], far[:, :, None, None, None])
+    rd = E.relative_disparity(smp.depths.clamp(nf[0], nf[1]), nf[0], nf[1])
+    enc = E.positional_encoding(rd, 10) @ par["depth_encoding.1.weight"].T \
+        + par["depth_encoding.1.bias"]
+    kv = (smp.features + enc).permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
+    x = f.permute(0, 1, 3, 4, 2).reshape(b * v * h * w, 1, c)
+    for i in range(2):
+        pre = f"transformer.layers.{i}.0."
+        x, _ = E.attention_layer(x, kv, par[pre + "norm.weight"], par[pre + "norm.bias"],
+                                 par[pre + "fn.to_q.weight"], par[pre + "fn.to_kv.weight"],
+                                 par[pre + "fn.to_out.0.weight"], par[pre + "fn.to_out.0.bias"],
+                                 heads)
+    x.square().mean().backward()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -105,13 +147,52 @@ def main():
     bg = torch.zeros((V, 3), device=dev)
     tgt_img = target.reshape(V, 3, *hw).to(dev)
 
-    def step():
-        for t in (means, cov, sh, op):
-            t.grad = None
+    # ---- path (A): paper encoder config (config/model/encoder/epipolar.yaml) ----
+    from pixelsplat_amd.encoder.epipolar_transformer import (EpipolarTransformer,
+                                                             EpipolarTransformerCfg,
+                                                             ImageSelfAttentionCfg)
+    torch.manual_seed(P.rank_seed(0, rank))
+    d_feat, down, n_samp, heads = 128, 4, 32, 4
+    et = EpipolarTransformer(EpipolarTransformerCfg(
+        self_attention=ImageSelfAttentionCfg(patch_size=4, num_octaves=10, num_layers=2,
+                                             num_heads=4, d_token=128, d_dot=128, d_mlp=256),
+        num_octaves=10, num_layers=2, num_heads=heads, num_samples=n_samp, d_dot=128, d_mlp=256,
+        downscale=down), d_feat, num_context_views=2).to(dev)
+    hA, wA = hw[0] // down, hw[1] // down
+    feat = torch.randn(b, 2, hA, wA, d_feat, device=dev).requires_grad_(True)   # channels-last
+    c_ext, c_intr = ctx.extrinsics.to(dev), ctx.intrinsics.to(dev)
+    c_near, c_far = ctx.near.to(dev), ctx.far.to(dev)
+    a_params = [p_ for n_, p_ in et.named_parameters()
+                if n_.startswith(("transformer.layers", "depth_encoding"))
+                and "self_attention" not in n_]
+
+    def path_a():
+        geo = et.epipolar_sampler.geometry(c_ext, c_intr, c_near, c_far, (hA, wA))
+        x = feat.reshape(-1, 1, d_feat)
+        for attn, _ff in et.transformer.layers:
+            x = et.fused_layer(attn, x, feat, geo) + x
+        return x.square().mean()
+
+    def path_b():
         img = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v)
-        loss = ((img - tgt_img) ** 2).mean()
+        return ((img - tgt_img) ** 2).mean()
+
+    def zero_grads():
+        for t in (means, cov, sh, op, feat, *a_params):
+            t.grad = None
+
+    def step(a=True, b_=True):
+        zero_grads()
+        loss = (path_a() if a else 0.0) + (path_b() if b_ else 0.0)
         loss.backward()
-        return img
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
 
     # D = sum of tile-list lengths (reported; enters the algorithmic-bytes figure)
     img, aux = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v,
@@ -139,6 +220,9 @@ def main():
     lib.ps_profile_enable(0)
     _lib.check(lib.ps_profile_collect(tot_ms, launches), "ps_profile_collect")
     elapsed = P.max_over_ranks(elapsed, world, dev)
+    # outside the contract's timed region: each path alone
+    ms_b = timed(lambda: step(a=False), args.steps)
+    ms_a = timed(lambda: step(b_=False), args.steps)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -147,15 +231,25 @@ def main():
                                                           int(launches[i])) for i in range(ng)}
         # algorithmic bytes per launch (DESIGN.md "kernels"): the reference-algorithm figure of
         # SURVEY.md 8(d), attributed per kernel; one launch covers all V views of the batch.
-        P = hw[0] * hw[1]
+        npix = hw[0] * hw[1]
         alg = {
             "preprocess_forward": 392.0 * G * V,
             "depth_sort": 48.0 * D_total,
             "tile_bins": 0.0,
-            "tiles_forward": 36.0 * D_total + 20.0 * P * V,
-            "tiles_backward": 76.0 * D_total + 20.0 * P * V,
+            "tiles_forward": 36.0 * D_total + 20.0 * npix * V,
+            "tiles_backward": 76.0 * D_total + 20.0 * npix * V,
             "preprocess_backward": 728.0 * G * V,
         }
+        # (A): compulsory HBM bytes of the folded formulation per launch; these
+        # kernels are VALU/latency bound, the figures are there to show how far from HBM
+        RA, TA, PA = b * 2 * hA * wA, n_samp, 20
+        fm = 4.0 * b * 2 * hA * wA * d_feat
+        alg.update({
+            "epipolar_geometry": RA * (24.0 + 25.0 + 16.0 * TA),
+            "epipolar_attention_forward": fm + RA * (12.0 * TA + 4.0 * heads * (2 * d_feat + 2 * PA + TA)),
+            "epipolar_attention_backward": fm + RA * (12.0 * TA + 4.0 * heads * (2 * d_feat + 2 * PA + 2 * TA)),
+            "epipolar_feature_grad": fm + RA * (8.0 * TA + 4.0 * heads * (2 * d_feat + 2 * TA)),
+        })
         dom = max(alg, key=lambda k: groups[k][0])
         dom_ms = groups[dom][0]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
@@ -166,7 +260,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"re10k 2-view, {hw[0]}x{hw[1]}, batch_size={b} per GPU, {v} target "
-                            f"views/scene (BASELINE.json configs[1]): rasterizer fwd+bwd (B)",
+                            f"views/scene (BASELINE.json configs[1]): epipolar sampler + 2 "
+                            f"cross-attention layers on [{b},2,{d_feat},{hA},{wA}] (A) + "
+                            f"rasterizer (B), fwd+bwd",
+                "epipolar_rays": b * 2 * hA * wA, "epipolar_samples_per_ray": n_samp,
                 "gaussians_per_scene": G, "views_per_step_per_gpu": V,
                 "tile_list_entries_D": D_total, "visible_gaussian_views": n_visible,
                 "D_over_GV": round(D_total / (G * V), 3), "parallelism": f"dp{world}",
@@ -178,9 +275,18 @@ def main():
                 "algorithmic_bytes_per_launch": alg[dom],
             },
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},
+            "kernel_launches_per_step": {k: groups[k][1] / args.steps for k in groups},
+            "paths": {
+                "raster_only_ms_per_step": round(ms_b, 3),
+                "raster_only_views_per_s": round(V / ms_b * 1e3 * world, 1),
+                "epipolar_only_ms_per_step": round(ms_a, 3),
+                "epipolar_reference_equivalent_tflops": round(
+                    3.0 * 2 * (2.0 * RA * (2 * d_feat * 512 + TA * d_feat * 1024 + 2 * 4 * TA * 128))
+                    / (ms_a * 1e-3) / 1e12, 1),
+            },
             "whole_path": {
-                "algorithmic_bytes_per_step": (1120.0 * G + 40.0 * P) * V + 160.0 * D_total,
-                "hbm_frac": round(((1120.0 * G + 40.0 * P) * V + 160.0 * D_total)
+                "algorithmic_bytes_per_step": (1120.0 * G + 40.0 * npix) * V + 160.0 * D_total,
+                "hbm_frac": round(((1120.0 * G + 40.0 * npix) * V + 160.0 * D_total)
                                   / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
@@ -189,6 +295,14 @@ def main():
                   / gpu_images.size).numpy()
             nv = min(args.cpu_views, V)
             cb, parity = cpu_baseline(g, tgt, vps_np, hw, nv, gpu_images, dL)
+            t_a = cpu_baseline_epipolar(et, feat, ctx, n_samp, heads)       # one scene
+            t_step = b * t_a + V / cb["value"]
+            cb["raster_only_views_per_s"] = round(cb["value"], 3)
+            cb["epipolar_s_per_scene"] = round(t_a, 2)
+            cb["value"] = V / t_step
+            cb["sample"] += (f"; (A) oracle/epipolar_ref.py (unfused, torch CPU autograd) on 1 of "
+                             f"{b} scenes, fwd+bwd, {t_a:.1f} s; value = {V} views / "
+                             f"({b} x scene time + {V} x view time)")
             out["cpu_baseline"] = cb
             out["parity_vs_oracle"] = parity
         print(json.dumps(out), flush=True)

@@ -742,8 +742,7 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                                   const uint8_t* flags, const float* rd, const float* qt,
                                   const float* attn, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
-                                  float* de, float* ds, float* dfmap, uint32_t* boxes,
-                                  hipStream_t st) {
+                                  float* de, float* ds, hipStream_t st) {
   if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
@@ -757,9 +756,16 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
   } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO
-  if (dfmap != nullptr) {
+  return PS_OK;
+}
+
+int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint8_t* flags,
+                                 const float* qt, const float* attn, const float* dfbar,
+                                 const float* ds, float* dfmap, uint32_t* boxes, hipStream_t st) {
+  if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
+  {
     if (boxes == nullptr || dm.w > 255 || dm.h > 255) return PS_ERR_BAD_ARG;
-    const size_t n_ro = rays * (dm.v - 1);
+    const size_t n_ro = (size_t)dm.b * dm.v * dm.h * dm.w * (dm.v - 1);
     hipLaunchKernelGGL(epipolar_ray_box_kernel, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
                        0, st, dm, xy, flags, boxes);
     constexpr int TS = 4;

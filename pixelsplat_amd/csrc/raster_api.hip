@@ -11,9 +11,12 @@ using namespace ps;
 namespace {
 
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
-enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET, G_COUNT };
+enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET,
+             G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_COUNT };
 const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
-                                    "tiles_backward", "preprocess_backward", "memset"};
+                                    "tiles_backward", "preprocess_backward", "memset",
+                                    "epipolar_geometry", "epipolar_attention_forward",
+                                    "epipolar_attention_backward", "epipolar_feature_grad"};
 std::atomic<int> g_profile_on{0};
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
@@ -245,6 +248,7 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
   if (!c2w || !w2c || !k || !k_inv || !near || !far || !origins || !directions || !segments ||
       !flags || !xy_sample || !depth || !rel_disparity)
     return PS_ERR_BAD_ARG;
+  Scope sc(G_EPI_GEOM, (hipStream_t)stream);
   launch_epipolar_geometry(b, v, h, w, s, c2w, w2c, k, k_inv, near, far, origins, directions,
                            segments, flags, xy_sample, depth, rel_disparity,
                            (hipStream_t)stream);
@@ -278,6 +282,7 @@ int ps_epipolar_attention_forward(const PsEpipolarDesc* d, const float* fmap,
   if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !u || !fbar ||
       !pbar || !abar || !attn)
     return PS_ERR_BAD_ARG;
+  Scope sc(G_EPI_FWD, (hipStream_t)stream);
   if (int rc = launch_epipolar_attn_forward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
                                             qt, u, e, scale, fbar, pbar, abar, attn,
                                             (hipStream_t)stream))
@@ -295,10 +300,19 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
   if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !dfbar ||
       !dpbar || !dabar || !dqt || !du || !de || !ds || (dfmap && !ray_boxes))
     return PS_ERR_BAD_ARG;
-  if (int rc = launch_epipolar_attn_backward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
-                                             qt, attn, dfbar, dpbar, dabar, scale, dqt, du, de,
-                                             ds, dfmap, ray_boxes, (hipStream_t)stream))
-    return rc;
+  {
+    Scope sc(G_EPI_BWD, (hipStream_t)stream);
+    if (int rc = launch_epipolar_attn_backward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
+                                               qt, attn, dfbar, dpbar, dabar, scale, dqt, du, de,
+                                               ds, (hipStream_t)stream))
+      return rc;
+  }
+  if (dfmap) {
+    Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
+    if (int rc = launch_epipolar_feature_grad(to_dims(d), xy_sample, flags, qt, attn, dfbar, ds,
+                                              dfmap, ray_boxes, (hipStream_t)stream))
+      return rc;
+  }
   return check_launch();
 }
 

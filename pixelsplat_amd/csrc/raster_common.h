@@ -154,8 +154,10 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                                   const uint8_t* flags, const float* rd, const float* qt,
                                   const float* attn, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
-                                  float* de, float* ds, float* dfmap, uint32_t* boxes,
-                                  hipStream_t st);
+                                  float* de, float* ds, hipStream_t st);
+int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint8_t* flags,
+                                 const float* qt, const float* attn, const float* dfbar,
+                                 const float* ds, float* dfmap, uint32_t* boxes, hipStream_t st);
 
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }

@@ -141,6 +141,21 @@ class EpipolarTransformer(nn.Module):
         if num_context_views > 2:
             self.view_embeddings = nn.Embedding(num_context_views, d_in)
 
+    def fused_layer(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None) -> Tensor:
+        """PreNorm(Attention)(x, z=kv) (pre_norm.py:34-35, attention.py:54-70) on the HIP path;
+        `attn` is one `layer[0]` of `self.transformer.layers`, fmap is channels-last."""
+        a = attn.fn
+        c = fmap.shape[-1]
+        lin = self.depth_encoding[1]
+        to_out = a.to_out[0] if isinstance(a.to_out, nn.Sequential) else None
+        return fused_cross_attention(
+            attn.norm(x), fmap, geo, w_q=a.to_q.weight, w_kv=a.to_kv.weight,
+            w_out=(to_out.weight if to_out is not None else
+                   torch.eye(c, device=x.device, dtype=x.dtype)),
+            b_out=(to_out.bias if to_out is not None else None), heads=a.heads,
+            depth_w=lin.weight, depth_b=lin.bias, octaves=self.cfg.num_octaves,
+            view_emb=view_emb)
+
     def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor, materialize_sampling: bool = False,
                 view_shuffle: Optional[Tensor] = None) -> tuple[Tensor, EpipolarSampling]:
@@ -161,7 +176,6 @@ class EpipolarTransformer(nn.Module):
                 view_shuffle = torch.randperm(v - 1, device=features.device)
             view_emb = self.view_embeddings(view_shuffle)
 
-        lin = self.depth_encoding[1]
         hooked = any(len(layer[0].fn.attend._forward_hooks) > 0 for layer in self.transformer.layers)
         need_kv = hooked or materialize_sampling
         sampled = gather_features(fmap, geo) if need_kv else None
@@ -179,14 +193,7 @@ class EpipolarTransformer(nn.Module):
                     kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
                 y = attn(x, z=kv)
             else:
-                to_out = a.to_out[0] if isinstance(a.to_out, nn.Sequential) else None
-                y = fused_cross_attention(
-                    attn.norm(x), fmap, geo, w_q=a.to_q.weight, w_kv=a.to_kv.weight,
-                    w_out=(to_out.weight if to_out is not None else
-                           torch.eye(c, device=x.device, dtype=x.dtype)),
-                    b_out=(to_out.bias if to_out is not None else None), heads=a.heads,
-                    depth_w=lin.weight, depth_b=lin.bias, octaves=self.cfg.num_octaves,
-                    view_emb=view_emb)
+                y = self.fused_layer(attn, x, fmap, geo, view_emb)
             x = y + x
             x = ff(x, b=b, v=v, h=h, w=w) + x
         features = x.reshape(b, v, h, w, c).permute(0, 1, 4, 2, 3)

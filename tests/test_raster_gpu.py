@@ -201,6 +201,30 @@ def test_full_size_properties(gpu_device):
     assert (np.abs(img - img2) > 1e-5).mean() < 1e-3
 
 
+def test_full_size_image_vs_oracle(gpu_device):
+    """BASELINE configs[1] geometry (256x256, G = 393216, one scene, 4 views) against the
+    oracle.  The blend has hard thresholds (alpha >= 1/255, T >= 1e-4) on values that go
+    through exp(): v_exp_f32 and libm round differently in the last bit, so out of ~200k
+    pixels x 400 Gaussians a handful of tests flip.  A flip adds or removes ONE
+    minimum-alpha contribution (<= 1/255 * T * colour).  Stated bar: every value within
+    1e-4 except at most 1e-4 of them, and those within 5e-3; PSNR > 100 dB."""
+    hw = (256, 256)
+    ctx, tgt, g, target = make_workload(1, hw, seed=0)
+    img, aux, _ = _batched_hip(g, tgt, hw, gpu_device)
+    vps = aux["view_params"].cpu().numpy()
+    n_over, n_all, worst, mse = 0, 0, 0.0, []
+    for v in range(img.shape[0]):
+        st = R.forward(H=hw[0], W=hw[1], **oracle_view_inputs(g, tgt, 0, v, view_params=vps[v]))
+        err = np.abs(img[v] - st.image)
+        n_over += int((err > IMG_TOL).sum())
+        n_all += err.size
+        worst = max(worst, float(err.max()))
+        mse.append(float(((np.clip(img[v], 0, 1) - np.clip(st.image, 0, 1)) ** 2).mean()))
+    assert n_over <= 1e-4 * n_all, (n_over, n_all)
+    assert worst < 5e-3, worst
+    assert -10 * np.log10(max(np.mean(mse), 1e-30)) > 100.0
+
+
 def test_empty_and_degenerate(gpu_device):
     sc = small_scene(8, (32, 32), seed=1, dtype=np.float32)
     sc["means"][:, 2] = -1.0  # everything behind the camera
