@@ -67,6 +67,11 @@ def load():
         raise HipExtensionMissing(
             f"{LIB_PATH} not found: build it with `python -m pixelsplat_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no non-HIP fallback for this path.")
+    # torch ships its own libamdhip64; it has to be in the process BEFORE this library is
+    # dlopen-ed so that both resolve to the same HIP runtime (otherwise kernels registered with
+    # one runtime are launched on streams of the other: "HIP launch failed")
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):
