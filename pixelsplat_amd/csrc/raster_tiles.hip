@@ -425,7 +425,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
           any |= ok;
         }
       }
-      if (__any(any) && !(d.reserved & 1)) {
+      if (__any(any)) {
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         wave_sum9_to_lane63(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b);
         if (lane == 63) {
@@ -439,7 +439,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     }
     wave_lds_sync();
     // lane j finalises entry j: one set of 9 atomics per (tile, Gaussian)
-    if ((uint32_t)lane < m && lds.gsum[lane][9] != 0.f && !(d.reserved & 2)) {
+    if ((uint32_t)lane < m && lds.gsum[lane][9] != 0.f) {
       const uint32_t slot = (b_head + lane) & (kQB - 1);
       const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
       const float* gs = lds.gsum[lane];
@@ -486,9 +486,7 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  PsRasterDesc dd = d;
-  if (const char* e = getenv("PS_DEBUG_BWD")) dd.reserved = atoi(e);   // perf experiments only
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, dd, records, tile_order,
+  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order,
                      tile_ranges,
                      point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
                      grad2d, tile_grads);
