@@ -237,6 +237,15 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap
                                    float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
                                    void* stream);
 
+/* C[m][n] = sum_k A[k][m] B[k][n] in fp32 (v_mfma_f32_32x32x2_f32), split over k with a
+ * fixed-order reduction: the weight gradients of the folded attention matrices
+ * (dW = dY^T X over all rays; autograd of the Linear layers at attention.py:36-45,
+ * epipolar_transformer.py:61-66).  A, B row-major with leading dimensions lda >= m,
+ * ldb >= n (multiples of 4, 16-byte aligned), n % 4 == 0.  workspace: ps_gemm_tn_workspace_bytes. */
+size_t ps_gemm_tn_workspace_bytes(int32_t m, int32_t n, int32_t k);
+int ps_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda, const float* b,
+                   int32_t ldb, float* c, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents
  * on the caller's stream; ps_profile_collect synchronises those events, ADDS the elapsed

@@ -12,11 +12,12 @@ namespace {
 
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
 enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET,
-             G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_COUNT };
+             G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_GEMM_TN, G_COUNT };
 const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
                                     "tiles_backward", "preprocess_backward", "memset",
                                     "epipolar_geometry", "epipolar_attention_forward",
-                                    "epipolar_attention_backward", "epipolar_feature_grad"};
+                                    "epipolar_attention_backward", "epipolar_feature_grad",
+                                    "gemm_tn_splitk"};
 std::atomic<int> g_profile_on{0};
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
@@ -313,6 +314,21 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
                                               dfmap, ray_boxes, (hipStream_t)stream))
       return rc;
   }
+  return check_launch();
+}
+
+size_t ps_gemm_tn_workspace_bytes(int32_t m, int32_t n, int32_t k) {
+  return (m > 0 && n > 0 && k > 0) ? gemm_tn_workspace_bytes(m, n, k) : 0;
+}
+
+int ps_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda, const float* b,
+                   int32_t ldb, float* c, void* workspace, size_t workspace_bytes, void* stream) {
+  if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || !workspace || lda < m || ldb < n)
+    return PS_ERR_BAD_ARG;
+  if (workspace_bytes < gemm_tn_workspace_bytes(m, n, k)) return PS_ERR_WORKSPACE;
+  Scope sc(G_GEMM_TN, (hipStream_t)stream);
+  if (int rc = launch_gemm_tn(m, n, k, a, lda, b, ldb, c, (float*)workspace, (hipStream_t)stream))
+    return rc;
   return check_launch();
 }
 

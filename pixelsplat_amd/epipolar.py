@@ -86,6 +86,49 @@ def gather_features(fmap_nhwc: Tensor, geo: EpipolarGeometry) -> Tensor:
     return out
 
 
+def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
+    """a [k, m], b [k, n] (fp32, row-major, last dim contiguous) -> a^T b [m, n] with the split-k
+    MFMA kernel (ps_gemm_tn_f32); deterministic."""
+    lib = _lib.load()
+    k, m = a.shape
+    n = b.shape[1]
+    if n % 4:                      # the kernel stores rows of C as float4
+        return gemm_tn(a, torch.nn.functional.pad(b, (0, -n % 4)))[:, :n]
+    if a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
+        a = torch.nn.functional.pad(a, (0, -m % 4))[:, :m] if m % 4 else a.contiguous()
+    if b.stride(1) != 1 or b.stride(0) % 4 or b.data_ptr() % 16:
+        b = b.contiguous()
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    ws_bytes = lib.ps_gemm_tn_workspace_bytes(m, n, k)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=a.device)
+    _lib.check(lib.ps_gemm_tn_f32(m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(ws),
+                                  C.c_size_t(ws_bytes), _stream()), "ps_gemm_tn_f32")
+    return c
+
+
+class _RayLinear(torch.autograd.Function):
+    """y = x W^T (+ bias) over all rays; the weight gradient dW = dy^T x is the long-k GEMM
+    hipBLASLt handles badly (gemm_tn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return x @ w.T if bias is None else torch.addmm(bias, x, w.T)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            ok = dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0
+            dw = gemm_tn(dy, x) if ok else dy.T @ x
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 class _FusedEpipolarAttention(torch.autograd.Function):
     """(fmap, q~, u, e) -> (fbar, pbar, abar, attn); see csrc/epipolar_attention.hip."""
 
@@ -175,15 +218,15 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     if b_out is not None:
         bias = bias + b_out
     x2 = x.reshape(R, d_in)
-    qt = (x2 @ w_in[0].T).reshape(R, heads, c)
-    u = (x2 @ w_in[1].T).reshape(R, heads, P)
+    qt = _RayLinear.apply(x2, w_in[0], None).reshape(R, heads, c)
+    u = _RayLinear.apply(x2, w_in[1], None).reshape(R, heads, P)
     e = None if view_emb is None else (x2 @ w_in[2].T).reshape(R, heads, -1)
     dims = (b, v, h, w, s, c, heads, octaves)
     fbar, pbar, abar, attn = _FusedEpipolarAttention.apply(
         dims, float(dh) ** -0.5, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample, geo.flags,
         geo.rel_disparity, qt, u, e)
-    out = torch.addmm(bias, fbar.reshape(R, heads * c), w_o[0].T)
-    out = torch.addmm(out, pbar.reshape(R, heads * P), w_o[1].T)
+    out = _RayLinear.apply(fbar.reshape(R, heads * c), w_o[0], bias)
+    out = out + _RayLinear.apply(pbar.reshape(R, heads * P), w_o[1], None)
     if view_emb is not None:
         out = torch.addmm(out, abar.reshape(R, -1), w_o[2].T)
     out = out.reshape(R, 1, d_out)

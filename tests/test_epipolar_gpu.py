@@ -224,3 +224,26 @@ def test_epipolar_transformer_module_vs_reference_golden(gpu_device, name, v):
     out.sum().backward()
     missing = [n for n, p in net.named_parameters() if p.grad is None]
     assert missing == []
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 128, 4096), (128, 512, 1000), (80, 128, 777), (128, 80, 258),
+                                   (4, 4, 1), (130, 260, 513)])
+def test_gemm_tn_splitk(gpu_device, m, n, k):
+    """ps_gemm_tn_f32 (fp32 MFMA, split-k, fixed-order reduction) against a float64 product:
+    within fp32 accumulation error, and bit-reproducible."""
+    from pixelsplat_amd.epipolar import gemm_tn
+
+    gen = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(k, m, generator=gen)
+    b = torch.randn(k, n, generator=gen)
+    ref = (a.double().T @ b.double())
+    c1 = gemm_tn(a.to(gpu_device), b.to(gpu_device))
+    c2 = gemm_tn(a.to(gpu_device), b.to(gpu_device))
+    assert torch.equal(c1, c2)
+    err = (c1.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * k ** 0.5 * 4, err
+    # strided operand (a column block of a wider matrix), as autograd hands them over
+    wide = torch.randn(k, m + 8, generator=gen).to(gpu_device)
+    c3 = gemm_tn(wide[:, 4:4 + m], b.to(gpu_device))
+    ref3 = wide[:, 4:4 + m].cpu().double().T @ b.double()
+    assert (c3.cpu().double() - ref3).abs().max().item() < 2e-6 * k ** 0.5 * 4
