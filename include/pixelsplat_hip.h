@@ -212,7 +212,9 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
  *   e      float[R][heads][v-1]  q~_h . view_embedding[perm[ov]], or NULL
  * forward outputs  fbar[R][heads][c] = sum_i a_i feat_i, pbar[R][heads][P] = sum_i a_i pe_i,
  *                  abar[R][heads][v-1] = attention mass per other view, attn[R][heads][T].
- * backward inputs  dfbar, dpbar, dabar (same shapes); outputs dqt, du, de, ds (scratch
+ * backward inputs  the forward's attn, fbar, pbar, abar and dfbar, dpbar, dabar (same shapes:
+ *                  one pass over the tokens, dq~ = scale (sum a da feat - (sum a da) fbar));
+ *                  outputs dqt, du, de, ds (scratch
  *                  [R][heads][T]) and dfmap float[b*v][h][w][c] (written, not accumulated;
  *                  may be NULL; needs ray_boxes, a uint32[b*v*(v-1)*h*w] scratch).  No atomics
  *                  of any kind: one wave owns a 4x4 pixel tile of the gradient image in LDS,
@@ -232,10 +234,12 @@ int ps_epipolar_attention_forward(const PsEpipolarDesc* desc, const float* fmap,
 int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap,
                                    const float* xy_sample, const uint8_t* flags,
                                    const float* rel_disparity, const float* qt,
-                                   const float* attn, const float* dfbar, const float* dpbar,
-                                   const float* dabar, float scale, float* dqt, float* du,
-                                   float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
-                                   void* stream);
+                                   const float* attn, const float* fbar, const float* pbar,
+                                   const float* abar /* NULL when e was NULL */,
+                                   const float* dfbar, const float* dpbar,
+                                   const float* dabar /* may be NULL */, float scale,
+                                   float* dqt, float* du, float* de, float* ds, float* dfmap,
+                                   uint32_t* ray_boxes, void* stream);
 
 /* C[m][n] = sum_k A[k][m] B[k][n] in fp32 (v_mfma_f32_32x32x2_f32), split over k with a
  * fixed-order reduction: the weight gradients of the folded attention matrices

@@ -109,7 +109,7 @@ def load():
     lib.ps_epipolar_gather.restype = C.c_int
     lib.ps_epipolar_attention_forward.argtypes = [pe] + [vp] * 7 + [C.c_float] + [vp] * 5
     lib.ps_epipolar_attention_forward.restype = C.c_int
-    lib.ps_epipolar_attention_backward.argtypes = [pe] + [vp] * 9 + [C.c_float] + [vp] * 7
+    lib.ps_epipolar_attention_backward.argtypes = [pe] + [vp] * 12 + [C.c_float] + [vp] * 7
     lib.ps_epipolar_attention_backward.restype = C.c_int
     lib.ps_gemm_tn_workspace_bytes.argtypes = [C.c_int32] * 3
     lib.ps_gemm_tn_workspace_bytes.restype = C.c_size_t

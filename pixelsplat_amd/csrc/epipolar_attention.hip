@@ -150,71 +150,110 @@ epipolar_gather_kernel(AttnDims dm, const float* __restrict__ fmap,
 }
 
 // ------------------------------------------------------------------------------------
-// fused attention, one wave64 per ray
+// fused attention, one wave64 per ray, tokens streamed in chunks of 8 (online softmax)
 // ------------------------------------------------------------------------------------
-// Wave-private LDS (floats): feat [T][c+4] | pe [T][Ps] | token records [T][8] | rd [T].
-// The row strides (c+4, Ps) are odd multiples of 4 floats so that the 128-bit reads of the
-// token-per-lane passes are bank-conflict free.
+// Wave-private LDS (floats): token records [T][8] | rd [T] | raw scores [4][T] |
+// feature chunk [8][4*S4] | encoding chunk [8][Ps]  -- 7.5 KB at the paper config, so the
+// occupancy is set by registers (the whole-ray staging of the previous version needed 20 KB
+// and ran at 2 waves/SIMD, 30 % of the VALU issue rate).
 //
-// Lane roles change between phases, which is what keeps the kernel off the VALU-issue floor
-// (the first version did everything lanes<->channels and spent its time in per-token
-// cross-lane reductions and 20-lane sinf calls):
-//   A  lanes <-> tokens    token record: 4 clamped corner pixels + 4 bilinear weights
-//   B  lanes <-> (t, p)    positional encoding, all 64 lanes busy
-//   C  lanes <-> (t, 4 ch) gather, 64/LPT tokens per step, 16-byte loads
-//   D  lanes <-> tokens    scores: the folded query sits in SGPRs (uniform per ray), a lane
-//                          walks its token's row in LDS -- no cross-lane reduction at all
-//   E  lanes <-> tokens    softmax with two DPP reductions for all heads at once
-//   F  lanes <-> channels  context: the weights come out of the token lanes with v_readlane
-struct RayCtx {
-  int ray, r, v, ovn, T, P, Ps, cs, H;
-  size_t bv, bbase;
-  float *featS, *peS, *tokS, *rdS;
-};
+// Lane roles per phase:
+//   A  lanes <-> tokens         token record: 4 clamped corner pixels + 4 bilinear weights
+//   per chunk of 8 tokens:
+//   B  lanes <-> (token, p)     positional encoding (range-reduced sin, ~25 instructions)
+//   C  lanes <-> (token, 4 ch)  gather, 64/LPT tokens per step, 16-byte loads
+//   D  lanes <-> (token, slice) lane = 8*token + j owns the channel quads j, j+8, ... of its
+//                               token: partial dot products against the folded query held in
+//                               registers, then a 3-step DPP sum over j (8 lanes)
+//   E  8 score lanes            chunk max / sum by DPP, running max and normaliser
+//   F  lanes <-> channels       context accumulation; weights via v_readlane
+// The feature rows use a stride of S4 quads with S4 = 8 (mod 16): the 16 lanes of one pass
+// of a 128-bit LDS read then cover all 64 banks.
+constexpr int kChunk = 8;       // tokens per chunk
+constexpr int kUPL = 4;         // encoding dims per lane in phase D (P <= 32)
 
-__host__ __device__ inline int pe_stride(int P) {
-  int ps = (P + 3) & ~3;
-  if (((ps >> 2) & 1) == 0) ps += 4;
-  return ps;
+__host__ __device__ inline int pe_stride(int P) { return (P + 3) & ~3; }
+__host__ __device__ inline int feat_stride_quads(int c) {
+  int s4 = c / 4;
+  while ((s4 & 15) != 8) ++s4;
+  return s4;
 }
 __host__ __device__ inline size_t wave_lds_floats(int T, int c, int P) {
-  return (size_t)T * (c + 4 + pe_stride(P) + 8 + 1);
+  return (size_t)T * (8 + 1 + kMaxHeads) + (size_t)kChunk * (4 * feat_stride_quads(c) + pe_stride(P));
 }
 
-#define PS_DPPMAX4(ctrl)                     \
-  "v_max_f32_dpp %0, %0, %0 " ctrl "\n"      \
-  "v_max_f32_dpp %1, %1, %1 " ctrl "\n"      \
-  "v_max_f32_dpp %2, %2, %2 " ctrl "\n"      \
-  "v_max_f32_dpp %3, %3, %3 " ctrl "\n"
-// wave64 maxima of four values (results in lane 63).  No bound_ctrl: a lane whose DPP source
-// is outside its row keeps its own value, which is the identity for max.
-__device__ __forceinline__ void wave_max4_to_lane63(float& a, float& b, float& c, float& d) {
+struct RayCtx {
+  int ray, r, v, ovn, T, P, Ps, fs, H;
+  size_t bv, bbase;
+  float *tokS, *rdS, *scS, *featS, *peS;
+};
+
+#define PS_DPP4(op, ctrl)                \
+  op " %0, %0, %0 " ctrl "\n"            \
+  op " %1, %1, %1 " ctrl "\n"            \
+  op " %2, %2, %2 " ctrl "\n"            \
+  op " %3, %3, %3 " ctrl "\n"
+// sums over each aligned group of 8 lanes, result in the group's last lane (the other lanes
+// of the group end up with partial sums that may include the neighbouring group: unused)
+__device__ __forceinline__ void group8_sum4(float& a, float& b, float& c, float& d) {
   asm volatile(
       "s_nop 1\n"
-      PS_DPPMAX4("row_shr:1 row_mask:0xf bank_mask:0xf")
-      PS_DPPMAX4("row_shr:2 row_mask:0xf bank_mask:0xf")
-      PS_DPPMAX4("row_shr:4 row_mask:0xf bank_mask:0xf")
-      PS_DPPMAX4("row_shr:8 row_mask:0xf bank_mask:0xf")
-      PS_DPPMAX4("row_bcast:15 row_mask:0xa bank_mask:0xf")
-      PS_DPPMAX4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      PS_DPP4("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      PS_DPP4("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      PS_DPP4("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
       "s_nop 1\n"
       : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
-#undef PS_DPPMAX4
+// reductions over the eight lanes 7, 15, ..., 63 (result in lane 63)
+__device__ __forceinline__ void lanes8_sum4_to_lane63(float& a, float& b, float& c, float& d) {
+  asm volatile(
+      "s_nop 1\n"
+      PS_DPP4("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      PS_DPP4("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+      PS_DPP4("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 1\n"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void lanes8_max4_to_lane63(float& a, float& b, float& c, float& d) {
+  asm volatile(
+      "s_nop 1\n"
+      PS_DPP4("v_max_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+      PS_DPP4("v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+      PS_DPP4("v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 1\n"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef PS_DPP4
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// phases A-C: fills the wave's LDS with the gathered tokens and their encodings
-template <int LPT>
-__device__ __forceinline__ void stage_tokens(const AttnDims& dm, const RayCtx& k, int lane,
-                                             const float* __restrict__ fmap,
-                                             const float* __restrict__ xy,
-                                             const uint8_t* __restrict__ flags,
-                                             const float* __restrict__ rd) {
+__device__ __forceinline__ bool ray_setup(const AttnDims& dm, float* smem, RayCtx& k) {
   const int R = dm.h * dm.w;
-  // A
+  k.ovn = dm.v - 1; k.T = dm.s * k.ovn; k.P = 2 * dm.octaves; k.Ps = pe_stride(k.P);
+  k.fs = 4 * feat_stride_quads(dm.c); k.H = dm.heads;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  k.ray = (int)blockIdx.x * kAttnWaves + wv;
+  if (k.ray >= dm.b * dm.v * R) return false;
+  k.tokS = smem + (size_t)wv * wave_lds_floats(k.T, dm.c, k.P);
+  k.rdS = k.tokS + (size_t)k.T * 8;
+  k.scS = k.rdS + k.T;
+  k.featS = k.scS + (size_t)kMaxHeads * k.T;
+  k.peS = k.featS + (size_t)kChunk * k.fs;
+  k.r = k.ray % R;
+  k.bv = (size_t)(k.ray / R);
+  k.v = (int)(k.bv % dm.v);
+  k.bbase = k.bv - k.v;
+  return true;
+}
+
+// phase A: token records of the whole ray
+__device__ __forceinline__ void stage_records(const AttnDims& dm, const RayCtx& k, int lane,
+                                              const float* __restrict__ xy,
+                                              const uint8_t* __restrict__ flags,
+                                              const float* __restrict__ rd) {
+  const int R = dm.h * dm.w;
   for (int t = lane; t < k.T; t += kWave) {
     const int si = t / k.ovn, ov = t - si * k.ovn;
     const size_t ro = (k.bv * k.ovn + ov) * R + k.r;
@@ -240,20 +279,26 @@ __device__ __forceinline__ void stage_tokens(const AttnDims& dm, const RayCtx& k
     k.rdS[t] = rd[so];
   }
   wave_lds_sync();
-  // B
+}
+
+// phases B, C: encodings and gathered features of tokens [t0, t0 + 8) into the chunk buffers
+template <int CK>
+__device__ __forceinline__ void stage_chunk(const AttnDims& dm, const RayCtx& k, int lane, int t0,
+                                            const float* __restrict__ fmap) {
+  constexpr int LPT = CK / 4, TPS = kWave / LPT;
   const float inv_p = 1.0f / (float)k.P;
-  for (int idx = lane; idx < k.T * k.P; idx += kWave) {
-    const int t = (int)(((float)idx + 0.5f) * inv_p);
-    const int p = idx - t * k.P;
-    k.peS[t * k.Ps + p] = pe_value(k.rdS[t], p);
+  for (int idx = lane; idx < kChunk * k.P; idx += kWave) {
+    const int tl = (int)(((float)idx + 0.5f) * inv_p);
+    const int p = idx - tl * k.P;
+    const int t = min(t0 + tl, k.T - 1);
+    k.peS[tl * k.Ps + p] = pe_value(k.rdS[t], p);
   }
-  // C
-  constexpr int TPI = kWave / LPT;
   const int lt = lane / LPT, ch = (lane % LPT) * 4;
-#pragma unroll 2
-  for (int t0 = 0; t0 < k.T; t0 += TPI) {
-    const int t = t0 + lt;
-    if (t < k.T && ch < dm.c) {
+#pragma unroll
+  for (int s0 = 0; s0 < kChunk; s0 += TPS) {
+    const int tl = s0 + lt;
+    const int t = t0 + tl;
+    if (tl < kChunk && t < k.T && ch < dm.c) {
       const int4 off = *reinterpret_cast<const int4*>(k.tokS + t * 8);
       const float4 wt = *reinterpret_cast<const float4*>(k.tokS + t * 8 + 4);
       const float4 p0 = *reinterpret_cast<const float4*>(fmap + (size_t)off.x * dm.c + ch);
@@ -265,125 +310,136 @@ __device__ __forceinline__ void stage_tokens(const AttnDims& dm, const RayCtx& k
       f.y = fmaf(p3.y, wt.w, fmaf(p2.y, wt.z, fmaf(p1.y, wt.y, p0.y * wt.x)));
       f.z = fmaf(p3.z, wt.w, fmaf(p2.z, wt.z, fmaf(p1.z, wt.y, p0.z * wt.x)));
       f.w = fmaf(p3.w, wt.w, fmaf(p2.w, wt.z, fmaf(p1.w, wt.y, p0.w * wt.x)));
-      *reinterpret_cast<float4*>(k.featS + t * k.cs + ch) = f;
+      *reinterpret_cast<float4*>(k.featS + tl * k.fs + ch) = f;
     }
   }
   wave_lds_sync();
 }
 
-// phase D: out[g][h] = qrow_h . feat_t + urow_h . pe_t + erow_{h, ov(t)} for token
-// t = lane + 64 g.  qrow/urow/erow are wave-uniform pointers (scalar loads).
-__device__ __forceinline__ void token_scores(const AttnDims& dm, const RayCtx& k, int lane,
-                                             const float* __restrict__ qrow,
-                                             const float* __restrict__ urow,
-                                             const float* __restrict__ erow,
-                                             float (&out)[2][kMaxHeads]) {
-  int hsel[kMaxHeads];
-#pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) hsel[hh] = hh < k.H ? hh : 0;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) out[g][hh] = 0.f;
-    if (g * kWave >= k.T) continue;                       // uniform
-    const int t = min(lane + g * kWave, k.T - 1);
-    const float* frow = k.featS + t * k.cs;
-    float acc[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int ch = 0; ch < dm.c; ch += 4) {
-      const float4 f = *reinterpret_cast<const float4*>(frow + ch);
-#pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh) {
-        const float* qp = qrow + hsel[hh] * dm.c + ch;
-        acc[hh] = fmaf(qp[3], f.w, fmaf(qp[2], f.z, fmaf(qp[1], f.y, fmaf(qp[0], f.x, acc[hh]))));
-      }
-    }
-    const float* prow = k.peS + t * k.Ps;
-    for (int p = 0; p < k.P; ++p) {
-      const float pe = prow[p];
-#pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] = fmaf(urow[hsel[hh] * k.P + p], pe, acc[hh]);
-    }
-    if (erow != nullptr) {
-      const int ov = t % k.ovn;
-#pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] += erow[hsel[hh] * k.ovn + ov];
-    }
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) out[g][hh] = acc[hh];
-  }
-}
+// The "query" of phase D in registers: lane = 8*tl + j holds, for every head, the channel
+// quads j, j+8, ... and the encoding dims j, j+8, ... of the row vectors qrow / urow.
+template <int CK>
+struct QueryRegs {
+  static constexpr int QPL = CK / 32;
+  float q[kMaxHeads][QPL][4];
+  float u[kMaxHeads][kUPL];
+};
 
-// phase F: rows[h][:] = sum_t wgt_{h,t} feat_t, prow[h][:] = sum_t wgt pe_t,
-// orow[h][ov] = sum_{t: ov(t)=ov} wgt  (orow may be null)
-template <int LPT>
-__device__ __forceinline__ void weighted_context(const AttnDims& dm, const RayCtx& k, int lane,
-                                                 const float (&wgt)[2][kMaxHeads],
-                                                 float* __restrict__ rows,
-                                                 float* __restrict__ prow,
-                                                 float* __restrict__ orow) {
-  constexpr int CPL = LPT >= 16 ? LPT / 16 : 1;
-  const int c0 = lane * CPL;
-  const bool lane_c = c0 < dm.c;
-  float acc[kMaxHeads][CPL], pacc[kMaxHeads], oacc[kMaxHeads];
+template <int CK>
+__device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, int lane,
+                                           const float* __restrict__ qrow,
+                                           const float* __restrict__ urow, QueryRegs<CK>& Q) {
+  const int j = lane & 7;
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
-    pacc[hh] = 0.f; oacc[hh] = 0.f;
+    const int hs = hh < k.H ? hh : 0;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) acc[hh][i] = 0.f;
-  }
-  const int fo = lane_c ? c0 : 0, po = lane < k.P ? lane : 0;
-  int ov = 0;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int cnt = min(k.T - g * kWave, kWave);
-    for (int tl = 0; tl < cnt; ++tl) {
-      const int t = g * kWave + tl;
-      float f[CPL];
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) f[i] = k.featS[t * k.cs + fo + i];
-      const float pe = k.peS[t * k.Ps + po];
-      const bool mine = ov == lane;
-#pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh) {
-        const float a = lane_bcast(wgt[g][hh], tl);
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) acc[hh][i] = fmaf(a, f[i], acc[hh][i]);
-        pacc[hh] = fmaf(a, pe, pacc[hh]);
-        if (orow != nullptr) oacc[hh] += mine ? a : 0.f;
-      }
-      ov = ov + 1 == k.ovn ? 0 : ov + 1;
+    for (int i = 0; i < QueryRegs<CK>::QPL; ++i) {
+      const int ch = 4 * (j + 8 * i);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ch < dm.c && hh < k.H) v = *reinterpret_cast<const float4*>(qrow + (size_t)hs * dm.c + ch);
+      Q.q[hh][i][0] = v.x; Q.q[hh][i][1] = v.y; Q.q[hh][i][2] = v.z; Q.q[hh][i][3] = v.w;
     }
-  }
-  for (int hh = 0; hh < k.H; ++hh) {
-    if (lane_c) {
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) rows[(size_t)hh * dm.c + c0 + i] = acc[hh][i];
+    for (int i = 0; i < kUPL; ++i) {
+      const int p = j + 8 * i;
+      Q.u[hh][i] = (p < k.P && hh < k.H) ? urow[hs * k.P + p] : 0.f;
     }
-    if (lane < k.P) prow[hh * k.P + lane] = pacc[hh];
-    if (orow != nullptr && lane < k.ovn) orow[hh * k.ovn + lane] = oacc[hh];
   }
 }
 
-__device__ __forceinline__ bool ray_setup(const AttnDims& dm, float* smem, RayCtx& k) {
-  const int R = dm.h * dm.w;
-  k.ovn = dm.v - 1; k.T = dm.s * k.ovn; k.P = 2 * dm.octaves; k.Ps = pe_stride(k.P);
-  k.cs = dm.c + 4; k.H = dm.heads;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  k.ray = (int)blockIdx.x * kAttnWaves + wv;
-  if (k.ray >= dm.b * dm.v * R) return false;
-  k.featS = smem + (size_t)wv * wave_lds_floats(k.T, dm.c, k.P);
-  k.peS = k.featS + (size_t)k.T * k.cs;
-  k.tokS = k.peS + (size_t)k.T * k.Ps;
-  k.rdS = k.tokS + (size_t)k.T * 8;
-  k.r = k.ray % R;
-  k.bv = (size_t)(k.ray / R);
-  k.v = (int)(k.bv % dm.v);
-  k.bbase = k.bv - k.v;
-  return true;
+// phase D: out[h] = qrow_h . feat_t + urow_h . pe_t + erow_{h, ov(t)} for the chunk's token
+// tl = lane / 8, valid in the lanes with j == 7
+template <int CK>
+__device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k, int lane, int t0,
+                                             const QueryRegs<CK>& Q, const float* __restrict__ erow,
+                                             float (&out)[kMaxHeads]) {
+  const int tl = lane >> 3, j = lane & 7;
+  const float* frow = k.featS + tl * k.fs;
+  float acc[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < QueryRegs<CK>::QPL; ++i) {
+    const int ch = 4 * (j + 8 * i);
+    if (ch < dm.c) {
+      const float4 f = *reinterpret_cast<const float4*>(frow + ch);
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh)
+        acc[hh] = fmaf(Q.q[hh][i][3], f.w, fmaf(Q.q[hh][i][2], f.z,
+                  fmaf(Q.q[hh][i][1], f.y, fmaf(Q.q[hh][i][0], f.x, acc[hh]))));
+    }
+  }
+  const float* prow = k.peS + tl * k.Ps;
+#pragma unroll
+  for (int i = 0; i < kUPL; ++i) {
+    const int p = j + 8 * i;
+    const float pe = p < k.P ? prow[p] : 0.f;
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] = fmaf(Q.u[hh][i], pe, acc[hh]);
+  }
+  if (erow != nullptr && j == 0) {
+    const int ov = min(t0 + tl, k.T - 1) % k.ovn;
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh)
+      if (hh < k.H) acc[hh] += erow[hh * k.ovn + ov];
+  }
+  group8_sum4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) out[hh] = acc[hh];
 }
 
-template <int LPT>
+// phase F accumulators: lanes <-> channels
+template <int CK>
+struct ContextRegs {
+  static constexpr int CPL = CK >= 64 ? CK / 64 : 1;
+  float f[kMaxHeads][CPL], p[kMaxHeads], o[kMaxHeads];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      p[hh] = 0.f; o[hh] = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) f[hh][i] = 0.f;
+    }
+  }
+  __device__ __forceinline__ void scale(const float (&s)[kMaxHeads]) {
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      p[hh] *= s[hh]; o[hh] *= s[hh];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) f[hh][i] *= s[hh];
+    }
+  }
+};
+
+// phase F: acc += sum over the chunk's tokens of wgt_{h,t} (feat_t | pe_t | [ov(t) == lane]);
+// wgt lives in lane 8*tl + 7
+template <int CK>
+__device__ __forceinline__ void chunk_context(const AttnDims& dm, const RayCtx& k, int lane, int t0,
+                                              const float (&wgt)[kMaxHeads], bool with_o,
+                                              ContextRegs<CK>& A) {
+  constexpr int CPL = ContextRegs<CK>::CPL;
+  const int c0 = lane * CPL;
+  const int fo = c0 < dm.c ? c0 : 0, po = lane < k.P ? lane : 0;
+  const int n = min(kChunk, k.T - t0);
+  int ov = t0 % k.ovn;
+  for (int tl = 0; tl < n; ++tl) {
+    float f[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) f[i] = k.featS[tl * k.fs + fo + i];
+    const float pe = k.peS[tl * k.Ps + po];
+    const bool mine = ov == lane;
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      const float a = lane_bcast(wgt[hh], 8 * tl + 7);
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) A.f[hh][i] = fmaf(a, f[i], A.f[hh][i]);
+      A.p[hh] = fmaf(a, pe, A.p[hh]);
+      if (with_o) A.o[hh] += mine ? a : 0.f;
+    }
+    ov = ov + 1 == k.ovn ? 0 : ov + 1;
+  }
+}
+
+template <int CK>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
                              const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -392,88 +448,141 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
                              float scale, float* __restrict__ fbar, float* __restrict__ pbar,
                              float* __restrict__ abar, float* __restrict__ attn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CPL = ContextRegs<CK>::CPL;
   RayCtx k;
   if (!ray_setup(dm, smem, k)) return;
   const int lane = threadIdx.x & 63;
-  stage_tokens<LPT>(dm, k, lane, fmap, xy, flags, rd);
-
   const size_t rh = (size_t)k.ray * k.H;
-  float sc[2][kMaxHeads];
-  token_scores(dm, k, lane, qt + rh * dm.c, u + rh * k.P, e ? e + rh * k.ovn : nullptr, sc);
-  // E: softmax over the T tokens
-  float mx[kMaxHeads];
+  stage_records(dm, k, lane, xy, flags, rd);
+  QueryRegs<CK> Q;
+  load_query<CK>(dm, k, lane, qt + rh * dm.c, u + rh * k.P, Q);
+  const float* erow = e ? e + rh * k.ovn : nullptr;
+
+  ContextRegs<CK> A;
+  A.clear();
+  float m_run[kMaxHeads], l_run[kMaxHeads];
 #pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
-    sc[0][hh] = lane < k.T ? sc[0][hh] * scale : -__builtin_inff();
-    sc[1][hh] = lane + kWave < k.T ? sc[1][hh] * scale : -__builtin_inff();
-    mx[hh] = fmaxf(sc[0][hh], sc[1][hh]);
-  }
-  wave_max4_to_lane63(mx[0], mx[1], mx[2], mx[3]);
-  float sm[kMaxHeads];
+  for (int hh = 0; hh < kMaxHeads; ++hh) { m_run[hh] = -__builtin_inff(); l_run[hh] = 0.f; }
+  const bool score_lane = (lane & 7) == 7;
+
+  for (int t0 = 0; t0 < k.T; t0 += kChunk) {
+    stage_chunk<CK>(dm, k, lane, t0, fmap);
+    float sc[kMaxHeads];
+    chunk_scores<CK>(dm, k, lane, t0, Q, erow, sc);
+    const int t = t0 + (lane >> 3);
+    const bool live = score_lane && t < k.T;
+    float mx[kMaxHeads];
 #pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
-    const float m = lane_bcast(mx[hh], 63);
-    sc[0][hh] = lane < k.T ? __expf(sc[0][hh] - m) : 0.f;
-    sc[1][hh] = lane + kWave < k.T ? __expf(sc[1][hh] - m) : 0.f;
-    sm[hh] = sc[0][hh] + sc[1][hh];
-  }
-  wave_sum4_to_lane63(sm[0], sm[1], sm[2], sm[3]);
-#pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
-    const float inv = 1.0f / lane_bcast(sm[hh], 63);
-    sc[0][hh] *= inv; sc[1][hh] *= inv;
-    if (hh < k.H) {
-      if (lane < k.T) attn[(rh + hh) * k.T + lane] = sc[0][hh];
-      if (lane + kWave < k.T) attn[(rh + hh) * k.T + lane + kWave] = sc[1][hh];
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      sc[hh] = live ? sc[hh] * scale : -__builtin_inff();
+      if (live && hh < k.H) k.scS[hh * k.T + t] = sc[hh];
+      mx[hh] = sc[hh];
     }
+    lanes8_max4_to_lane63(mx[0], mx[1], mx[2], mx[3]);
+    float corr[kMaxHeads], ps[kMaxHeads];
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      const float m_new = fmaxf(m_run[hh], lane_bcast(mx[hh], 63));
+      corr[hh] = __expf(m_run[hh] - m_new);            // exp(-inf) = 0 on the first chunk
+      m_run[hh] = m_new;
+      sc[hh] = live ? __expf(sc[hh] - m_new) : 0.f;
+      ps[hh] = sc[hh];
+    }
+    lanes8_sum4_to_lane63(ps[0], ps[1], ps[2], ps[3]);
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh)
+      l_run[hh] = fmaf(l_run[hh], corr[hh], lane_bcast(ps[hh], 63));
+    A.scale(corr);
+    chunk_context<CK>(dm, k, lane, t0, sc, e != nullptr, A);
+    wave_lds_sync();        // the chunk buffers are overwritten by the next iteration
   }
-  weighted_context<LPT>(dm, k, lane, sc, fbar + rh * dm.c, pbar + rh * k.P,
-                        e ? abar + rh * k.ovn : nullptr);
+
+  const int c0 = lane * CPL;
+  for (int hh = 0; hh < k.H; ++hh) {
+    const float inv = 1.0f / l_run[hh];
+    if (c0 < dm.c) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) fbar[(rh + hh) * dm.c + c0 + i] = A.f[hh][i] * inv;
+    }
+    if (lane < k.P) pbar[(rh + hh) * k.P + lane] = A.p[hh] * inv;
+    if (e != nullptr && lane < k.ovn) abar[(rh + hh) * k.ovn + lane] = A.o[hh] * inv;
+    for (int t = lane; t < k.T; t += kWave)
+      attn[(rh + hh) * k.T + t] = __expf(k.scS[hh * k.T + t] - m_run[hh]) * inv;
+  }
 }
 
 // ------------------------------------------------------------------------------------
-// attention backward, per ray: dq~, du, de and the per-token coefficients the feature-map
-// scatter needs (ds = scale * a (da - sum a da))
+// attention backward, per ray, one pass over the tokens:
+//   da_t = dfbar . feat_t + dpbar . pe_t + dabar_{ov(t)},   dot = sum_t a_t da_t,
+//   ds_t = scale a_t (da_t - dot)                 (needed by the feature-map gradient)
+//   dq~  = sum_t ds_t feat_t = scale (sum_t a_t da_t feat_t - dot fbar)   and likewise du, de
+// so the weighted sums use w_t = a_t da_t, known per chunk, and the forward outputs
+// (fbar, pbar, abar) close the expression -- no second gather.
 // ------------------------------------------------------------------------------------
-template <int LPT>
+template <int CK>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
                               const float* __restrict__ xy, const uint8_t* __restrict__ flags,
                               const float* __restrict__ rd, const float* __restrict__ attn,
-                              const float* __restrict__ dfbar, const float* __restrict__ dpbar,
-                              const float* __restrict__ dabar, float scale,
-                              float* __restrict__ dqt, float* __restrict__ du,
+                              const float* __restrict__ fbar, const float* __restrict__ pbar,
+                              const float* __restrict__ abar, const float* __restrict__ dfbar,
+                              const float* __restrict__ dpbar, const float* __restrict__ dabar,
+                              float scale, float* __restrict__ dqt, float* __restrict__ du,
                               float* __restrict__ de, float* __restrict__ ds_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CPL = ContextRegs<CK>::CPL;
   RayCtx k;
   if (!ray_setup(dm, smem, k)) return;
   const int lane = threadIdx.x & 63;
-  stage_tokens<LPT>(dm, k, lane, fmap, xy, flags, rd);
-
   const size_t rh = (size_t)k.ray * k.H;
-  // da_{h,t} = dfbar_h . feat_t + dpbar_h . pe_t + dabar_{h,ov(t)}
-  float da[2][kMaxHeads];
-  token_scores(dm, k, lane, dfbar + rh * dm.c, dpbar + rh * k.P,
-               dabar ? dabar + rh * k.ovn : nullptr, da);
-  float a[2][kMaxHeads], dot[kMaxHeads];
+  stage_records(dm, k, lane, xy, flags, rd);
+  QueryRegs<CK> Q;
+  load_query<CK>(dm, k, lane, dfbar + rh * dm.c, dpbar + rh * k.P, Q);
+  const float* erow = dabar ? dabar + rh * k.ovn : nullptr;
+
+  ContextRegs<CK> A;
+  A.clear();
+  float dot[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
+  const bool score_lane = (lane & 7) == 7;
+  for (int t0 = 0; t0 < k.T; t0 += kChunk) {
+    stage_chunk<CK>(dm, k, lane, t0, fmap);
+    float da[kMaxHeads];
+    chunk_scores<CK>(dm, k, lane, t0, Q, erow, da);
+    const int t = t0 + (lane >> 3);
+    const bool live = score_lane && t < k.T;
 #pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
-    a[0][hh] = (hh < k.H && lane < k.T) ? attn[(rh + hh) * k.T + lane] : 0.f;
-    a[1][hh] = (hh < k.H && lane + kWave < k.T) ? attn[(rh + hh) * k.T + lane + kWave] : 0.f;
-    dot[hh] = fmaf(a[0][hh], da[0][hh], a[1][hh] * da[1][hh]);
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      const bool on = live && hh < k.H;
+      const float a = on ? attn[(rh + hh) * k.T + t] : 0.f;
+      if (on) k.scS[hh * k.T + t] = da[hh];
+      da[hh] = a * da[hh];
+      if (!on) da[hh] = 0.f;
+      dot[hh] += da[hh];
+    }
+    chunk_context<CK>(dm, k, lane, t0, da, true, A);
+    wave_lds_sync();
   }
   wave_sum4_to_lane63(dot[0], dot[1], dot[2], dot[3]);
-#pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
+  const int c0 = lane * CPL;
+  for (int hh = 0; hh < k.H; ++hh) {
     const float d = lane_bcast(dot[hh], 63);
-    da[0][hh] = scale * a[0][hh] * (da[0][hh] - d);
-    da[1][hh] = scale * a[1][hh] * (da[1][hh] - d);
-    if (hh < k.H) {
-      if (lane < k.T) ds_out[(rh + hh) * k.T + lane] = da[0][hh];
-      if (lane + kWave < k.T) ds_out[(rh + hh) * k.T + lane + kWave] = da[1][hh];
+    if (c0 < dm.c) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+        dqt[(rh + hh) * dm.c + c0 + i] =
+            scale * (A.f[hh][i] - d * fbar[(rh + hh) * dm.c + c0 + i]);
     }
+    if (lane < k.P) du[(rh + hh) * k.P + lane] = scale * (A.p[hh] - d * pbar[(rh + hh) * k.P + lane]);
+    if (lane < k.ovn) {
+      // abar is only produced when the view embedding exists; otherwise it is the softmax mass
+      // of the single other view, i.e. one
+      const float ab = abar ? abar[(rh + hh) * k.ovn + lane] : 1.0f;
+      de[(rh + hh) * k.ovn + lane] = scale * (A.o[hh] - d * ab);
+    }
+    for (int t = lane; t < k.T; t += kWave)
+      ds_out[(rh + hh) * k.T + t] =
+          scale * attn[(rh + hh) * k.T + t] * (k.scS[hh * k.T + t] - d);
   }
-  weighted_context<LPT>(dm, k, lane, da, dqt + rh * dm.c, du + rh * k.P, de + rh * k.ovn);
 }
 
 // ------------------------------------------------------------------------------------
@@ -692,7 +801,7 @@ static size_t attn_smem(const AttnDims& dm) {
 
 static bool attn_dims_ok(const AttnDims& dm) {
   return attn_smem(dm) <= 160 * 1024 && dm.heads >= 1 && dm.heads <= kMaxHeads &&
-         dm.s * (dm.v - 1) <= 128 && dm.s * (dm.v - 1) >= 1 && 2 * dm.octaves <= 64 &&
+         dm.s * (dm.v - 1) <= 128 && dm.s * (dm.v - 1) >= 1 && 2 * dm.octaves <= 8 * kUPL &&
          dm.octaves >= 1 && dm.c % 4 == 0 && dm.c >= 4 && dm.c <= 256 &&
          (size_t)dm.b * dm.v * dm.h * dm.w < (size_t)1 << 30;
 }
@@ -708,14 +817,11 @@ int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* x
   return PS_OK;
 }
 
-// lanes per token of the gather phase: c/4 rounded up to a power of two
-#define PS_BY_LPT(GO)                                  \
-  do {                                                 \
-    const int q = dm.c / 4;                            \
-    if (q <= 1) GO(1); else if (q <= 2) GO(2);         \
-    else if (q <= 4) GO(4); else if (q <= 8) GO(8);    \
-    else if (q <= 16) GO(16); else if (q <= 32) GO(32);\
-    else GO(64);                                       \
+// channel class of the attention kernels
+#define PS_BY_LPT(GO)                                            \
+  do {                                                           \
+    if (dm.c <= 32) GO(32); else if (dm.c <= 64) GO(64);         \
+    else if (dm.c <= 128) GO(128); else GO(256);                 \
   } while (0)
 
 int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const float* xy,
@@ -740,7 +846,8 @@ int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const fl
 
 int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const float* xy,
                                   const uint8_t* flags, const float* rd, const float* qt,
-                                  const float* attn, const float* dfbar, const float* dpbar,
+                                  const float* attn, const float* fbar, const float* pbar,
+                                  const float* abar, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
                                   float* de, float* ds, hipStream_t st) {
   if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
@@ -752,7 +859,8 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
     (void)hipFuncSetAttribute((const void*)epipolar_attn_backward_kernel<L>,                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
     hipLaunchKernelGGL(epipolar_attn_backward_kernel<L>, grid, block, sm, st, dm, fmap, xy,     \
-                       flags, rd, attn, dfbar, dpbar, dabar, scale, dqt, du, de, ds);           \
+                       flags, rd, attn, fbar, pbar, abar, dfbar, dpbar, dabar, scale, dqt, du,  \
+                       de, ds);                                                                 \
   } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO

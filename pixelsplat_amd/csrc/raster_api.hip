@@ -294,18 +294,19 @@ int ps_epipolar_attention_forward(const PsEpipolarDesc* d, const float* fmap,
 int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
                                    const float* xy_sample, const uint8_t* flags,
                                    const float* rel_disparity, const float* qt,
-                                   const float* attn, const float* dfbar, const float* dpbar,
+                                   const float* attn, const float* fbar, const float* pbar,
+                                   const float* abar, const float* dfbar, const float* dpbar,
                                    const float* dabar, float scale, float* dqt, float* du,
                                    float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
                                    void* stream) {
-  if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !dfbar ||
-      !dpbar || !dabar || !dqt || !du || !de || !ds || (dfmap && !ray_boxes))
+  if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !fbar ||
+      !pbar || !dfbar || !dpbar || !dqt || !du || !de || !ds || (dfmap && !ray_boxes))
     return PS_ERR_BAD_ARG;
   {
     Scope sc(G_EPI_BWD, (hipStream_t)stream);
     if (int rc = launch_epipolar_attn_backward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
-                                               qt, attn, dfbar, dpbar, dabar, scale, dqt, du, de,
-                                               ds, (hipStream_t)stream))
+                                               qt, attn, fbar, pbar, abar, dfbar, dpbar, dabar,
+                                               scale, dqt, du, de, ds, (hipStream_t)stream))
       return rc;
   }
   if (dfmap) {

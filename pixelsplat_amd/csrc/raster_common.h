@@ -152,7 +152,8 @@ int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const fl
                                  float* pbar, float* abar, float* attn, hipStream_t st);
 int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const float* xy,
                                   const uint8_t* flags, const float* rd, const float* qt,
-                                  const float* attn, const float* dfbar, const float* dpbar,
+                                  const float* attn, const float* fbar, const float* pbar,
+                                  const float* abar, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
                                   float* de, float* ds, hipStream_t st);
 int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint8_t* flags,

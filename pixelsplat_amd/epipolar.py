@@ -151,14 +151,14 @@ class _FusedEpipolarAttention(torch.autograd.Function):
             C.c_float(scale), _p(fbar), _p(pbar), _p(abar), _p(attn), _stream()),
             "ps_epipolar_attention_forward")
         ctx.dims, ctx.scale, ctx.has_e = dims, scale, e is not None
-        ctx.save_for_backward(fmap, xy, flags, rd, qt, attn)
+        ctx.save_for_backward(fmap, xy, flags, rd, qt, attn, fbar, pbar, abar)
         ctx.mark_non_differentiable(attn)
         return fbar, pbar, abar, attn
 
     @staticmethod
     def backward(ctx, dfbar, dpbar, dabar, _dattn):
         lib = _lib.load()
-        fmap, xy, flags, rd, qt, attn = ctx.saved_tensors
+        fmap, xy, flags, rd, qt, attn, fbar, pbar, abar = ctx.saved_tensors
         b, v, h, w, s, c, heads, octaves = ctx.dims
         d = _desc(*ctx.dims)
         R, T, P, ov = b * v * h * w, s * (v - 1), 2 * octaves, v - 1
@@ -172,8 +172,10 @@ class _FusedEpipolarAttention(torch.autograd.Function):
             dfmap = torch.empty_like(fmap)
             boxes = torch.empty((R * ov,), dtype=torch.int32, device=fmap.device)
         _lib.check(lib.ps_epipolar_attention_backward(
-            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), _p(qt), _p(attn),
-            _p(dfbar.contiguous()), _p(dpbar.contiguous()), _p(dabar.contiguous()),
+            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), _p(qt), _p(attn), _p(fbar), _p(pbar),
+            _p(abar if ctx.has_e else None),
+            _p(dfbar.contiguous()), _p(dpbar.contiguous()),
+            _p(dabar.contiguous() if ctx.has_e else None),
             C.c_float(ctx.scale), _p(dqt), _p(du), _p(de), _p(ds), _p(dfmap), _p(boxes),
             _stream()),
             "ps_epipolar_attention_backward")
