@@ -153,7 +153,8 @@ epipolar_gather_kernel(AttnDims dm, const float* __restrict__ fmap,
 // fused attention, one wave64 per ray, tokens streamed in chunks of 8 (online softmax)
 // ------------------------------------------------------------------------------------
 // Wave-private LDS (floats): token records [T][8] | rd [T] | raw scores [4][T] |
-// feature chunk [8][4*S4] | encoding chunk [8][Ps]  -- 7.5 KB at the paper config, so the
+// feature chunk [8][4*S4] | encoding chunk [8][Ps] | folded query [4][c]  -- 9.5 KB at the
+// paper config (4 waves/SIMD; the query in registers cost 64 VGPRs and one wave), so the
 // occupancy is set by registers (the whole-ray staging of the previous version needed 20 KB
 // and ran at 2 waves/SIMD, 30 % of the VALU issue rate).
 //
@@ -170,7 +171,7 @@ epipolar_gather_kernel(AttnDims dm, const float* __restrict__ fmap,
 // The feature rows use a stride of S4 quads with S4 = 8 (mod 16): the 16 lanes of one pass
 // of a 128-bit LDS read then cover all 64 banks.
 constexpr int kChunk = 8;       // tokens per chunk
-constexpr int kUPL = 4;         // encoding dims per lane in phase D (P <= 32)
+constexpr int kUPL = 3;         // encoding dims per lane in phase D (P <= 24)
 
 __host__ __device__ inline int pe_stride(int P) { return (P + 3) & ~3; }
 __host__ __device__ inline int feat_stride_quads(int c) {
@@ -179,13 +180,14 @@ __host__ __device__ inline int feat_stride_quads(int c) {
   return s4;
 }
 __host__ __device__ inline size_t wave_lds_floats(int T, int c, int P) {
-  return (size_t)T * (8 + 1 + kMaxHeads) + (size_t)kChunk * (4 * feat_stride_quads(c) + pe_stride(P));
+  return (size_t)T * (8 + 1 + kMaxHeads) + (size_t)kChunk * (4 * feat_stride_quads(c) + pe_stride(P)) +
+         (size_t)kMaxHeads * c;
 }
 
 struct RayCtx {
   int ray, r, v, ovn, T, P, Ps, fs, H;
   size_t bv, bbase;
-  float *tokS, *rdS, *scS, *featS, *peS;
+  float *tokS, *rdS, *scS, *featS, *peS, *qS;
 };
 
 #define PS_DPP4(op, ctrl)                \
@@ -228,6 +230,10 @@ __device__ __forceinline__ void lanes8_max4_to_lane63(float& a, float& b, float&
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// marks a wave-uniform value as such (it then lives in an SGPR)
+__device__ __forceinline__ float uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 
 __device__ __forceinline__ bool ray_setup(const AttnDims& dm, float* smem, RayCtx& k) {
   const int R = dm.h * dm.w;
@@ -241,6 +247,7 @@ __device__ __forceinline__ bool ray_setup(const AttnDims& dm, float* smem, RayCt
   k.scS = k.rdS + k.T;
   k.featS = k.scS + (size_t)kMaxHeads * k.T;
   k.peS = k.featS + (size_t)kChunk * k.fs;
+  k.qS = k.peS + (size_t)kChunk * k.Ps;
   k.r = k.ray % R;
   k.bv = (size_t)(k.ray / R);
   k.v = (int)(k.bv % dm.v);
@@ -316,56 +323,52 @@ __device__ __forceinline__ void stage_chunk(const AttnDims& dm, const RayCtx& k,
   wave_lds_sync();
 }
 
-// The "query" of phase D in registers: lane = 8*tl + j holds, for every head, the channel
-// quads j, j+8, ... and the encoding dims j, j+8, ... of the row vectors qrow / urow.
-template <int CK>
+// The "query" of phase D: the channel part goes to LDS ([h][c]; the 8 token lanes of a slice
+// read the same address, a broadcast), the encoding part stays in registers: lane = 8*tl + j
+// holds the dims j, j+8, ... of urow for every head.
 struct QueryRegs {
-  static constexpr int QPL = CK / 32;
-  float q[kMaxHeads][QPL][4];
   float u[kMaxHeads][kUPL];
 };
 
-template <int CK>
 __device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, int lane,
                                            const float* __restrict__ qrow,
-                                           const float* __restrict__ urow, QueryRegs<CK>& Q) {
+                                           const float* __restrict__ urow, QueryRegs& Q) {
+  for (int i = lane * 4; i < k.H * dm.c; i += kWave * 4)
+    *reinterpret_cast<float4*>(k.qS + i) = *reinterpret_cast<const float4*>(qrow + i);
   const int j = lane & 7;
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
     const int hs = hh < k.H ? hh : 0;
-#pragma unroll
-    for (int i = 0; i < QueryRegs<CK>::QPL; ++i) {
-      const int ch = 4 * (j + 8 * i);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ch < dm.c && hh < k.H) v = *reinterpret_cast<const float4*>(qrow + (size_t)hs * dm.c + ch);
-      Q.q[hh][i][0] = v.x; Q.q[hh][i][1] = v.y; Q.q[hh][i][2] = v.z; Q.q[hh][i][3] = v.w;
-    }
 #pragma unroll
     for (int i = 0; i < kUPL; ++i) {
       const int p = j + 8 * i;
       Q.u[hh][i] = (p < k.P && hh < k.H) ? urow[hs * k.P + p] : 0.f;
     }
   }
+  wave_lds_sync();
 }
 
 // phase D: out[h] = qrow_h . feat_t + urow_h . pe_t + erow_{h, ov(t)} for the chunk's token
 // tl = lane / 8, valid in the lanes with j == 7
 template <int CK>
 __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k, int lane, int t0,
-                                             const QueryRegs<CK>& Q, const float* __restrict__ erow,
+                                             const QueryRegs& Q, const float* __restrict__ erow,
                                              float (&out)[kMaxHeads]) {
   const int tl = lane >> 3, j = lane & 7;
   const float* frow = k.featS + tl * k.fs;
   float acc[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < QueryRegs<CK>::QPL; ++i) {
+  for (int i = 0; i < CK / 32; ++i) {
     const int ch = 4 * (j + 8 * i);
     if (ch < dm.c) {
       const float4 f = *reinterpret_cast<const float4*>(frow + ch);
 #pragma unroll
-      for (int hh = 0; hh < kMaxHeads; ++hh)
-        acc[hh] = fmaf(Q.q[hh][i][3], f.w, fmaf(Q.q[hh][i][2], f.z,
-                  fmaf(Q.q[hh][i][1], f.y, fmaf(Q.q[hh][i][0], f.x, acc[hh]))));
+      for (int hh = 0; hh < kMaxHeads; ++hh) {
+        if (hh < k.H) {
+          const float4 q = *reinterpret_cast<const float4*>(k.qS + hh * dm.c + ch);
+          acc[hh] = fmaf(q.w, f.w, fmaf(q.z, f.z, fmaf(q.y, f.y, fmaf(q.x, f.x, acc[hh]))));
+        }
+      }
     }
   }
   const float* prow = k.peS + tl * k.Ps;
@@ -454,8 +457,8 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   const int lane = threadIdx.x & 63;
   const size_t rh = (size_t)k.ray * k.H;
   stage_records(dm, k, lane, xy, flags, rd);
-  QueryRegs<CK> Q;
-  load_query<CK>(dm, k, lane, qt + rh * dm.c, u + rh * k.P, Q);
+  QueryRegs Q;
+  load_query(dm, k, lane, qt + rh * dm.c, u + rh * k.P, Q);
   const float* erow = e ? e + rh * k.ovn : nullptr;
 
   ContextRegs<CK> A;
@@ -482,8 +485,8 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     float corr[kMaxHeads], ps[kMaxHeads];
 #pragma unroll
     for (int hh = 0; hh < kMaxHeads; ++hh) {
-      const float m_new = fmaxf(m_run[hh], lane_bcast(mx[hh], 63));
-      corr[hh] = __expf(m_run[hh] - m_new);            // exp(-inf) = 0 on the first chunk
+      const float m_new = uniform(fmaxf(m_run[hh], lane_bcast(mx[hh], 63)));
+      corr[hh] = uniform(__expf(m_run[hh] - m_new));   // exp(-inf) = 0 on the first chunk
       m_run[hh] = m_new;
       sc[hh] = live ? __expf(sc[hh] - m_new) : 0.f;
       ps[hh] = sc[hh];
@@ -491,14 +494,16 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     lanes8_sum4_to_lane63(ps[0], ps[1], ps[2], ps[3]);
 #pragma unroll
     for (int hh = 0; hh < kMaxHeads; ++hh)
-      l_run[hh] = fmaf(l_run[hh], corr[hh], lane_bcast(ps[hh], 63));
+      l_run[hh] = uniform(fmaf(l_run[hh], corr[hh], lane_bcast(ps[hh], 63)));
     A.scale(corr);
     chunk_context<CK>(dm, k, lane, t0, sc, e != nullptr, A);
     wave_lds_sync();        // the chunk buffers are overwritten by the next iteration
   }
 
   const int c0 = lane * CPL;
-  for (int hh = 0; hh < k.H; ++hh) {
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) {
+    if (hh >= k.H) break;
     const float inv = 1.0f / l_run[hh];
     if (c0 < dm.c) {
 #pragma unroll
@@ -536,8 +541,8 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   const int lane = threadIdx.x & 63;
   const size_t rh = (size_t)k.ray * k.H;
   stage_records(dm, k, lane, xy, flags, rd);
-  QueryRegs<CK> Q;
-  load_query<CK>(dm, k, lane, dfbar + rh * dm.c, dpbar + rh * k.P, Q);
+  QueryRegs Q;
+  load_query(dm, k, lane, dfbar + rh * dm.c, dpbar + rh * k.P, Q);
   const float* erow = dabar ? dabar + rh * k.ovn : nullptr;
 
   ContextRegs<CK> A;
@@ -564,7 +569,9 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   }
   wave_sum4_to_lane63(dot[0], dot[1], dot[2], dot[3]);
   const int c0 = lane * CPL;
-  for (int hh = 0; hh < k.H; ++hh) {
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) {
+    if (hh >= k.H) break;
     const float d = lane_bcast(dot[hh], 63);
     if (c0 < dm.c) {
 #pragma unroll
