@@ -602,14 +602,14 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
 // tools/lds_atomic_microbench.hip) against ~10 clocks for a plain ds_read/add/ds_write.
 // So the scatter is turned into an owner-computes pass with NO atomics:
 //   * one wave owns a TS x TS pixel tile of one source image, all channels, in LDS
-//     ((TS*TS + 4) * c floats); lanes <-> channels, so one LDS read-modify-write touches 64
+//     ((TS*TS + 1) * c floats); lanes <-> channels, so one LDS read-modify-write touches 64
 //     distinct addresses and a wave is the only writer of its tile;
 //   * the wave culls the rays of the casting views against its tile with a packed pixel
 //     bounding box of each ray's samples (64 rays per test, one ballot), then, for a hit,
 //     computes the corner records of the ray's samples lanes <-> samples and walks only the
 //     samples that really touch the tile (second ballot);
-//   * corners outside the tile/image are redirected to four dummy pixels with weight 0, so
-//     the four read-modify-writes of a sample are branch free and independent.
+//   * corners outside the tile/image are redirected to a dummy pixel with weight 0 (it stays
+//     zero), so the four read-modify-writes of a sample are branch free and independent.
 // The summation order is fixed (view, ray, sample, corner): the gradient is bit-reproducible,
 // which atomics never were.  Every pixel is written exactly once; dfmap needs no memset.
 // ------------------------------------------------------------------------------------
@@ -653,7 +653,7 @@ __device__ __forceinline__ int lane_bcast_i(int v, int lane) {
 }
 
 constexpr int kDfWaves = 4;   // waves per tile, each with a private copy (rays interleaved)
-constexpr int kDfChunk = 4096; // rays culled per pass (bounds the per-wave hit list)
+constexpr int kDfChunk = 2048; // rays culled per pass (bounds the per-wave hit list)
 
 template <int CPL, int TS>
 __global__ void __launch_bounds__(kDfWaves* kWave)
@@ -661,7 +661,7 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
                       const uint32_t* __restrict__ boxes, const float* __restrict__ attn,
                       const float* __restrict__ ds, const float* __restrict__ dfbar,
                       const float* __restrict__ qt, float* __restrict__ dfmap) {
-  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][(TS*TS + 4)][c]
+  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][(TS*TS + 1)][c]
   using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
   const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
@@ -674,13 +674,13 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
   const int c0 = lane * CPL;
   const bool lane_c = c0 < dm.c;
   const int cl = lane_c ? c0 : 0;
-  float* tile = tiles + (size_t)wv * (TS * TS + 4) * dm.c;
-  for (int i = lane; i < (TS * TS + 4) * dm.c; i += kWave) tile[i] = 0.f;
+  float* tile = tiles + (size_t)wv * (TS * TS + 1) * dm.c;
+  for (int i = lane; i < (TS * TS + 1) * dm.c; i += kWave) tile[i] = 0.f;
   wave_lds_sync();
 
   // per-wave list of the rays whose box overlaps the tile (uint16 ray index inside the
   // current super-chunk of kDfChunk rays), behind the tile copies
-  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * (TS * TS + 4) * dm.c) +
+  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * (TS * TS + 1) * dm.c) +
                    (size_t)wv * (kDfChunk / kDfWaves);
   const int ngroups = (dm.s + kWave - 1) / kWave;                // 1 when s <= 64
 
@@ -702,7 +702,28 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
         const int r = r0 + lane;
         const uint32_t box = r < R ? boxes[ro0 + r] : 0x00FF00FFu;
         const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
-        const bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+        bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+        if (hit) {
+          // exact test: a sample touches the tile iff its pixel position lies in
+          // [tx0 - 1, tx1 + 1) x [ty0 - 1, ty1 + 1); the samples lie on the segment between
+          // the first and the last one (Liang-Barsky clip, 0.02 px of slack for rounding)
+          const size_t so = (ro0 + r) * dm.s;
+          const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * so);
+          const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (so + dm.s - 1));
+          const Corner ca = corner_of(p0.x, p0.y, dm.w, dm.h), cb = corner_of(p1.x, p1.y, dm.w, dm.h);
+          const float ax = (float)ca.x0 + ca.wx, ay = (float)ca.y0 + ca.wy;
+          const float dx = (float)cb.x0 + cb.wx - ax, dy = (float)cb.y0 + cb.wy - ay;
+          const float xlo = (float)tx0 - 1.02f, xhi = (float)tx1 + 1.02f;
+          const float ylo = (float)ty0 - 1.02f, yhi = (float)ty1 + 1.02f;
+          float ta = 0.f, tb = 1.f;
+          auto clip = [&](float pp, float qq) {       // pp * t <= qq
+            if (pp == 0.f) { if (qq < 0.f) tb = -1.f; return; }
+            const float rr = qq / pp;
+            if (pp < 0.f) ta = fmaxf(ta, rr); else tb = fminf(tb, rr);
+          };
+          clip(-dx, ax - xlo); clip(dx, xhi - ax); clip(-dy, ay - ylo); clip(dy, yhi - ay);
+          hit = ta <= tb;
+        }
         const uint64_t m = __ballot(hit);
         if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)(r - chunk0);
         count += __popcll(m);
@@ -740,7 +761,7 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
           const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
           const bool in = tok && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
           const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
-          off[cr] = (in ? (yy - ty0) * TS + (xx - tx0) : TS * TS + cr) * dm.c;
+          off[cr] = (in ? (yy - ty0) * TS + (xx - tx0) : TS * TS) * dm.c;
           wt[cr] = in ? wx * wy : 0.f;
           any |= in;
         }
@@ -761,7 +782,7 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
                   df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
               }
             }
-            // four distinct pixels (or distinct dummies): reads first, then the writes
+            // four distinct pixels (or the all-zero dummy): reads first, then the writes
             V* dst[4]; V val[4];
 #pragma unroll
             for (int cr = 0; cr < 4; ++cr) {
@@ -793,7 +814,7 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < kDfWaves; ++k)
-      acc += tiles[((size_t)k * (TS * TS + 4) + py * TS + px) * dm.c + ch];
+      acc += tiles[((size_t)k * (TS * TS + 1) + py * TS + px) * dm.c + ch];
     out[((size_t)(ty0 + py) * dm.w + tx0 + px) * dm.c + ch] = acc;
   }
 }
@@ -886,7 +907,7 @@ int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint
     constexpr int TS = 4;
     const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
     dim3 g2((unsigned)(dm.b * dm.v * tiles)), b2(kDfWaves * kWave);
-    const size_t sm2 = (size_t)kDfWaves * (TS * TS + 4) * dm.c * sizeof(float) +
+    const size_t sm2 = (size_t)kDfWaves * (TS * TS + 1) * dm.c * sizeof(float) +
                        kDfChunk * sizeof(uint16_t);
 #define PS_DF(CPL)                                                                              \
   hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, xy, boxes, attn,    \
