@@ -1,6 +1,8 @@
 // Per-view stable LSD radix sort of (depth bits -> Gaussian id), 4 passes x 8 bits, all
-// views in one launch per pass.  Culled Gaussians carry key 0xFFFFFFFF and land behind the
-// n_vis[v] visible ones.  Stability + ids emitted in ascending order give exactly the order
+// views in one launch per pass.  Culled Gaussians carry key 0xFFFFFFFF: the first pass drops
+// them (it is also the compaction: n_vis[v] = its histogram total), the other three passes
+// only touch the n_vis[v] visible entries (40 % of the Gaussians at the paper config).
+// Stability + ids emitted in ascending order give exactly the order
 // of the reference's (tile | depth) stable sort restricted to any tile, so
 // the per-tile lists the tile kernels walk are bit-identical to the reference's bins.
 //
@@ -12,32 +14,51 @@
 
 namespace ps {
 
+
+template <bool FIRST>
 __global__ void __launch_bounds__(kSortThreads)
 sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist, int G,
-                 int nblk, int shift) {
+                 int nblk, int shift, const uint32_t* __restrict__ n_vis) {
   __shared__ uint32_t h[256];
   const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
-  h[t] = 0;
-  __syncthreads();
-  const uint32_t* k = keys + (size_t)v * G;
+  const int limit = FIRST ? G : (int)n_vis[v];
   const int base = blk * kSortChunk;
+  if (base < limit) {
+    h[t] = 0;
+    __syncthreads();
+    const uint32_t* k = keys + (size_t)v * G;
 #pragma unroll
-  for (int i = 0; i < kSortItems; ++i) {
-    const int p = base + i * kSortThreads + t;
-    if (p < G) atomicAdd(&h[(k[p] >> shift) & 0xFFu], 1u);
+    for (int i = 0; i < kSortItems; ++i) {
+      const int p = base + i * kSortThreads + t;
+      if (p < limit) {
+        const uint32_t key = k[p];
+        if (!FIRST || key != kCulledKey) atomicAdd(&h[(key >> shift) & 0xFFu], 1u);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  block_hist[((size_t)v * 256 + t) * nblk + blk] = h[t];
+  block_hist[((size_t)v * 256 + t) * nblk + blk] = base < limit ? h[t] : 0u;
 }
 
-// one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order
+// one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order.
+// A thread owns one digit row; the row is walked 16 entries at a time so that the loads of a
+// group are in flight together (a plain running loop is a chain of nblk dependent latencies).
 __global__ void __launch_bounds__(256)
 sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restrict__ n_vis) {
   __shared__ uint32_t tot[256];
   const int v = blockIdx.x, dgt = threadIdx.x;
   uint32_t* row = block_hist + ((size_t)v * 256 + dgt) * nblk;
   uint32_t sum = 0;
-  for (int b = 0; b < nblk; ++b) { const uint32_t c = row[b]; row[b] = sum; sum += c; }
+  for (int b0 = 0; b0 < nblk; b0 += 16) {
+    uint32_t c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nblk ? row[b0 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (b0 + i < nblk) row[b0 + i] = sum;
+      sum += c[i];
+    }
+  }
   tot[dgt] = sum;
   __syncthreads();
   // exclusive scan over 256 digit totals (Hillis-Steele in LDS)
@@ -49,21 +70,31 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restri
     __syncthreads();
   }
   const uint32_t excl = x - sum;
-  for (int b = 0; b < nblk; ++b) row[b] += excl;
-  // last pass only: keys below the top digit 0xFF are exactly the visible ones (depth > 0
-  // has top byte <= 0x7F; culled entries carry 0xFFFFFFFF) -> n_vis without any atomics
-  if (n_vis != nullptr && dgt == 255) n_vis[v] = excl;
+  for (int b0 = 0; b0 < nblk; b0 += 16) {
+    uint32_t c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nblk ? row[b0 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (b0 + i < nblk) row[b0 + i] = c[i] + excl;
+  }
+  // first pass only: its histogram skipped the culled keys, so the grand total is the number
+  // of visible Gaussians of the view -- n_vis without any atomics
+  if (n_vis != nullptr && dgt == 255) n_vis[v] = x;
 }
 
 template <bool IOTA_VALS>
 __global__ void __launch_bounds__(kSortThreads)
 sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                    const uint32_t* __restrict__ block_hist, int G, int nblk, int shift) {
+                    const uint32_t* __restrict__ block_hist, int G, int nblk, int shift,
+                    const uint32_t* __restrict__ n_vis) {
   __shared__ uint32_t cnt[4][256];   // per-wave running digit counts
   __shared__ uint32_t base[4][256];  // global start of (wave, digit)
   const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   const int w = t >> 6, lane = t & 63;
+  const int limit = IOTA_VALS ? G : (int)n_vis[v];
+  if (blk * kSortChunk >= limit) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i) cnt[i][t] = 0;
   __syncthreads();
@@ -75,8 +106,9 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     const int p = start + i * kWave + lane;
-    const bool valid = p < G;
+    bool valid = p < limit;
     key[i] = valid ? keys_in[vo + p] : 0u;
+    if (IOTA_VALS) valid = valid && key[i] != kCulledKey;
     val[i] = valid ? (IOTA_VALS ? (uint32_t)p : vals_in[vo + p]) : 0u;
     const uint32_t dg = (key[i] >> shift) & 0xFFu;
     uint64_t mask = __ballot(valid);
@@ -92,7 +124,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
       rank[i] = prefix + r;
       if (r == 0) cnt[w][dg] = prefix + (uint32_t)__popcll(mask);
     } else {
-      rank[i] = 0;
+      rank[i] = kCulledKey;       // dropped
     }
     wave_lds_sync();
   }
@@ -105,8 +137,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
-    const int p = start + i * kWave + lane;
-    if (p < G) {
+    if (rank[i] != kCulledKey) {
       const uint32_t dg = (key[i] >> shift) & 0xFFu;
       const uint32_t pos = base[w][dg] + rank[i];
       keys_out[vo + pos] = key[i];
@@ -135,15 +166,20 @@ void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint
   uint32_t* vin = nullptr; uint32_t* vout = vals_b;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = pass * 8;
-    hipLaunchKernelGGL(sort_hist_kernel, grid, block, 0, st, kin, block_hist, m.G, m.nblk, shift);
+    if (pass == 0)
+      hipLaunchKernelGGL(sort_hist_kernel<true>, grid, block, 0, st, kin, block_hist, m.G, m.nblk,
+                         shift, n_vis);
+    else
+      hipLaunchKernelGGL(sort_hist_kernel<false>, grid, block, 0, st, kin, block_hist, m.G, m.nblk,
+                         shift, n_vis);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(256), 0, st, block_hist, m.nblk,
-                       pass == 3 ? n_vis : (uint32_t*)nullptr);
+                       pass == 0 ? n_vis : (uint32_t*)nullptr);
     if (pass == 0)
       hipLaunchKernelGGL(sort_scatter_kernel<true>, grid, block, 0, st, kin, vin, kout, vout,
-                         block_hist, m.G, m.nblk, shift);
+                         block_hist, m.G, m.nblk, shift, n_vis);
     else
       hipLaunchKernelGGL(sort_scatter_kernel<false>, grid, block, 0, st, kin, vin, kout, vout,
-                         block_hist, m.G, m.nblk, shift);
+                         block_hist, m.G, m.nblk, shift, n_vis);
     // ping-pong: keys a<->b ; vals: (iota)->b->a->b->sorted_idx
     uint32_t* tk = kin; kin = kout; kout = tk;
     vin = vout;
