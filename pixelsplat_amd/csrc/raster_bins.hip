@@ -29,7 +29,7 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
   const int v = blockIdx.y, b = blockIdx.x;
   const uint32_t n = n_vis[v];
   const uint32_t base = (uint32_t)b * kBinChunk;
-  if (base >= n) return;  // counts were zeroed by the host-side memset
+  if (base >= n) return;  // bins past the visible prefix are never read
   const uint32_t cnt = n - base < (uint32_t)kBinChunk ? n - base : (uint32_t)kBinChunk;
   const size_t vo = (size_t)v * m.G;
   for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
@@ -68,18 +68,25 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
 // per (view, tile): exclusive prefix of counts over the view's blocks (in place) and the
 // tile total
 __global__ void __launch_bounds__(256)
-bin_scan_blocks_kernel(PsRasterDesc d, uint32_t* __restrict__ counts,
-                       uint32_t* __restrict__ tile_ranges) {
+bin_scan_blocks_kernel(PsRasterDesc d, const uint32_t* __restrict__ n_vis,
+                       uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_ranges) {
   const Dims m = make_dims(d);
   const int vt = blockIdx.x * blockDim.x + threadIdx.x;
   if (vt >= m.V * m.tiles) return;
   const int v = vt / m.tiles, t = vt % m.tiles;
+  // only the bins holding visible entries were counted; 16 loads in flight per step
+  const int nb = (int)((n_vis[v] + kBinChunk - 1) / kBinChunk);
+  uint32_t* col = counts + (size_t)v * m.nbin * m.tiles + t;
   uint32_t run = 0;
-  for (int b = 0; b < m.nbin; ++b) {
-    uint32_t* c = counts + ((size_t)v * m.nbin + b) * m.tiles + t;
-    const uint32_t k = *c;
-    *c = run;
-    run += k;
+  for (int b0 = 0; b0 < nb; b0 += 16) {
+    uint32_t c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nb ? col[(size_t)(b0 + i) * m.tiles] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (b0 + i < nb) col[(size_t)(b0 + i) * m.tiles] = run;
+      run += c[i];
+    }
   }
   tile_ranges[2 * (size_t)vt + 1] = run;
 }
@@ -158,13 +165,12 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
                       uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,
                       uint32_t* tile_order, hipStream_t st) {
   const Dims m = make_dims(d);
-  (void)hipMemsetAsync(counts, 0, (size_t)m.V * m.nbin * m.tiles * 4, st);
   dim3 grid(m.nbin, m.V);
   hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, d, sorted_rect,
                      (const uint32_t*)nullptr, n_vis, counts, (const uint32_t*)nullptr,
                      (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3((m.V * m.tiles + 255) / 256), dim3(256), 0, st,
-                     d, counts, tile_ranges);
+                     d, n_vis, counts, tile_ranges);
   hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, d, tile_ranges,
                      num_rendered, tile_order);
 }

@@ -37,25 +37,26 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
     }
     __syncthreads();
   }
-  block_hist[((size_t)v * 256 + t) * nblk + blk] = base < limit ? h[t] : 0u;
+  block_hist[((size_t)v * nblk + blk) * 256 + t] = base < limit ? h[t] : 0u;     // [v][blk][digit]
 }
 
 // one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order.
-// A thread owns one digit row; the row is walked 16 entries at a time so that the loads of a
-// group are in flight together (a plain running loop is a chain of nblk dependent latencies).
+// Storage is [v][block][digit], so a thread (= digit) walking its blocks reads coalesced
+// 1 KB rows, 16 at a time so that the loads of a group are in flight together (a plain
+// running loop over a digit-major array was a chain of nblk dependent, uncoalesced loads).
 __global__ void __launch_bounds__(256)
 sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restrict__ n_vis) {
   __shared__ uint32_t tot[256];
   const int v = blockIdx.x, dgt = threadIdx.x;
-  uint32_t* row = block_hist + ((size_t)v * 256 + dgt) * nblk;
+  uint32_t* row = block_hist + (size_t)v * nblk * 256 + dgt;     // element b at row[b * 256]
   uint32_t sum = 0;
   for (int b0 = 0; b0 < nblk; b0 += 16) {
     uint32_t c[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nblk ? row[b0 + i] : 0u;
+    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nblk ? row[(size_t)(b0 + i) * 256] : 0u;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      if (b0 + i < nblk) row[b0 + i] = sum;
+      if (b0 + i < nblk) row[(size_t)(b0 + i) * 256] = sum;
       sum += c[i];
     }
   }
@@ -73,10 +74,10 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restri
   for (int b0 = 0; b0 < nblk; b0 += 16) {
     uint32_t c[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nblk ? row[b0 + i] : 0u;
+    for (int i = 0; i < 16; ++i) c[i] = b0 + i < nblk ? row[(size_t)(b0 + i) * 256] : 0u;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (b0 + i < nblk) row[b0 + i] = c[i] + excl;
+      if (b0 + i < nblk) row[(size_t)(b0 + i) * 256] = c[i] + excl;
   }
   // first pass only: its histogram skipped the culled keys, so the grand total is the number
   // of visible Gaussians of the view -- n_vis without any atomics
@@ -130,7 +131,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   }
   __syncthreads();
   {
-    uint32_t b = block_hist[((size_t)v * 256 + t) * nblk + blk];
+    uint32_t b = block_hist[((size_t)v * nblk + blk) * 256 + t];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { base[i][t] = b; b += cnt[i][t]; }
   }
