@@ -37,31 +37,52 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
     if (WRITE) s_idx[i] = sorted_idx[vo + base + i];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < m.tiles; t += blockDim.x) {
+  // A wave owns 64 consecutive tiles = a band of tile rows.  Entries are first tested
+  // against the band, 64 at a time (one entry per lane, one ballot); only the survivors
+  // (a rect spans 1-2 tile rows, so ~1 in 4 at 256x256) are tested by every lane against
+  // its own tile.  Survivors are visited in ascending order, so the lists stay depth-sorted.
+  const int lane = threadIdx.x & 63;
+  for (int t0 = (int)threadIdx.x - lane; t0 < m.tiles; t0 += blockDim.x) {
+    const int t = t0 + lane;
+    const bool tile_ok = t < m.tiles;
     const uint32_t Tt = (uint32_t)(t % m.gx) | ((uint32_t)(t / m.gx) << 16);
     const uint32_t T1 = Tt + 0x00010001u;
-    uint32_t* c = counts + ((size_t)v * m.nbin + b) * m.tiles + t;
-    if (!WRITE) {
-      uint32_t k = 0;
-      for (uint32_t i = 0; i < cnt; ++i) k += rect_covers_packed(s_rect[i], Tt, T1) ? 1u : 0u;
-      *c = k;
-    } else {
-      uint32_t off = tile_ranges[2 * ((size_t)v * m.tiles + t)] + *c;
-      for (uint32_t i = 0; i < cnt; ++i) {
+    const uint32_t band_lo = (uint32_t)(t0 / m.gx);
+    const uint32_t band_hi = (uint32_t)(min(t0 + 63, m.tiles - 1) / m.gx);
+    uint32_t* c = counts + ((size_t)v * m.nbin + b) * m.tiles + (tile_ok ? t : 0);
+    uint32_t k = 0;
+    uint32_t off = 0;
+    if (WRITE && tile_ok) off = tile_ranges[2 * ((size_t)v * m.tiles + t)] + *c;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+      const uint32_t e = i0 + lane;
+      bool in_band = false;
+      if (e < cnt) {
+        const uint2 r = s_rect[e];
+        in_band = (r.x >> 16) <= band_hi && (r.y >> 16) > band_lo;
+      }
+      uint64_t hits = __ballot(in_band);
+      while (hits) {
+        const uint32_t i = i0 + (uint32_t)__builtin_ctzll(hits);
+        hits &= hits - 1;
         const uint2 r = s_rect[i];
-        if (rect_covers_packed(r, Tt, T1)) {
-          if (off < capacity) point_list[off] = s_idx[i];
-          // inverse map for Gaussians touching <= 4 tiles: where each of its tiles keeps it
-          const uint32_t wr = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
-          const uint32_t hr = (r.y >> 16) - (r.x >> 16);
-          if (wr * hr <= (uint32_t)kInvSlots) {
-            const uint32_t k = ((Tt >> 16) - (r.x >> 16)) * wr + ((Tt & 0xFFFFu) - (r.x & 0xFFFFu));
-            inv_slots[(vo + s_idx[i]) * kInvSlots + k] = off;
+        if (tile_ok && rect_covers_packed(r, Tt, T1)) {
+          if (!WRITE) {
+            ++k;
+          } else {
+            if (off < capacity) point_list[off] = s_idx[i];
+            // inverse map for Gaussians touching <= 4 tiles: where each of its tiles keeps it
+            const uint32_t wr = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
+            const uint32_t hr = (r.y >> 16) - (r.x >> 16);
+            if (wr * hr <= (uint32_t)kInvSlots) {
+              const uint32_t kk = ((Tt >> 16) - (r.x >> 16)) * wr + ((Tt & 0xFFFFu) - (r.x & 0xFFFFu));
+              inv_slots[(vo + s_idx[i]) * kInvSlots + kk] = off;
+            }
+            ++off;
           }
-          ++off;
         }
       }
     }
+    if (!WRITE && tile_ok) *c = k;
   }
 }
 
