@@ -657,7 +657,7 @@ constexpr int kDfChunk = 2048; // rays culled per pass (bounds the per-wave hit 
 
 template <int CPL, int TS>
 __global__ void __launch_bounds__(kDfWaves* kWave)
-epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
+epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
                       const uint32_t* __restrict__ boxes, const float* __restrict__ attn,
                       const float* __restrict__ ds, const float* __restrict__ dfbar,
                       const float* __restrict__ qt, float* __restrict__ dfmap) {
@@ -665,8 +665,15 @@ epipolar_dfmap_kernel(AttnDims dm, const float* __restrict__ xy,
   using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
   const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
-  const int tile_id = blockIdx.x % (tiles_x * tiles_y);
-  const int src_bv = blockIdx.x / (tiles_x * tiles_y);          // (b, source view)
+  // XCD-aware order: hardware hands block i to XCD i % 8, each with its own 4 MB L2.  A ray's
+  // rows (dfbar, q~: 4 KB) are needed by every tile its line crosses, so neighbouring tiles
+  // of one image must share an L2: XCD x works on the x-th contiguous eighth of the tiles
+  // (measured: 3 GB -> see DESIGN.md of memory-side fetches per launch before the remap).
+  const int per_xcd = (int)gridDim.x / 8;
+  const int work = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+  if (work >= n_work) return;
+  const int tile_id = work % (tiles_x * tiles_y);
+  const int src_bv = work / (tiles_x * tiles_y);                // (b, source view)
   const int b = src_bv / dm.v, sv = src_bv % dm.v;
   const int tx0 = (tile_id % tiles_x) * TS, ty0 = (tile_id / tiles_x) * TS;
   const int tx1 = min(tx0 + TS, dm.w) - 1, ty1 = min(ty0 + TS, dm.h) - 1;
@@ -906,11 +913,13 @@ int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint
                        0, st, dm, xy, flags, boxes);
     constexpr int TS = 4;
     const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
-    dim3 g2((unsigned)(dm.b * dm.v * tiles)), b2(kDfWaves * kWave);
+    const int n_work = dm.b * dm.v * tiles;
+    dim3 g2((unsigned)((n_work + 7) / 8 * 8)), b2(kDfWaves * kWave);
     const size_t sm2 = (size_t)kDfWaves * (TS * TS + 1) * dm.c * sizeof(float) +
                        kDfChunk * sizeof(uint16_t);
 #define PS_DF(CPL)                                                                              \
-  hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, xy, boxes, attn,    \
+  hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, n_work, xy, boxes,  \
+                     attn,                                                                      \
                      ds, dfbar, qt, dfmap)
     if (dm.c <= 64) PS_DF(1); else if (dm.c <= 128) PS_DF(2); else PS_DF(4);
 #undef PS_DF

@@ -147,15 +147,22 @@ geometry_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
 
 // SH -> RGB for the (view, Gaussian) pairs that survived the cull.
 // LDS_SH: slab staged through LDS (3K odd and <= 75); otherwise direct per-lane loads.
+// This kernel is a stream over the SH array (300 B per Gaussian, 0.83 GB at the paper
+// config) and bandwidth follows occupancy: measured with tools/stream_microbench.hip, MI355X
+// reads 6.1 TB/s at full occupancy but 3.8-4.5 TB/s when LDS limits a CU to 8 waves.  So a
+// wave takes only 32 Gaussians (9.6 KB slab, 16 waves/CU) and uses its two half-waves for the
+// even / odd views of the same Gaussians.
 template <int DEG, bool LDS_SH>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kWave, LDS_SH ? 4 : 1)
 color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
                      const float* __restrict__ sh, const float* __restrict__ view_params,
                      const int32_t* __restrict__ radii, float* __restrict__ records) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
+  constexpr int GPW = LDS_SH ? 32 : kWave;          // Gaussians per wave
   const int G = d.n_gaussians, vps = d.views_per_scene, K = d.sh_coeffs;
   const int lane = threadIdx.x;
-  const int g = blockIdx.x * kWave + lane;
+  const int gl = lane % GPW, part = lane / GPW, parts = kWave / GPW;
+  const int g = blockIdx.x * GPW + gl;
   const int s = blockIdx.y;
   const bool active = g < G;
   const size_t sg = (size_t)s * G + (active ? g : 0);
@@ -168,19 +175,18 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
   if (vps > 32) vis_bits = active ? 0xFFFFFFFFu : 0u;
   if (__ballot(vis_bits != 0u) == 0ull) return;
 
-  __shared__ float slab[LDS_SH ? kWave * 75 : 1];
+  __shared__ __attribute__((aligned(16))) float slab[LDS_SH ? GPW * 75 + 4 : 4];
   const float* my_sh;
   if (LDS_SH) {
-    const size_t g0 = (size_t)s * G + (size_t)blockIdx.x * kWave;
-    const int rem = G - (int)(blockIdx.x * kWave);
-    const int nflt = (rem < kWave ? rem : kWave) * S3;
+    const size_t g0 = (size_t)s * G + (size_t)blockIdx.x * GPW;
+    const int rem = G - (int)(blockIdx.x * GPW);
+    const int nflt = (rem < GPW ? rem : GPW) * S3;
     const float* src = sh + g0 * (size_t)S3;
     if ((reinterpret_cast<size_t>(src) & 15) == 0) {
       const float4* src4 = reinterpret_cast<const float4*>(src);
       for (int i = lane; i * 4 < nflt; i += kWave) {
         if (i * 4 + 3 < nflt) {
-          const float4 x = src4[i];
-          slab[i * 4] = x.x; slab[i * 4 + 1] = x.y; slab[i * 4 + 2] = x.z; slab[i * 4 + 3] = x.w;
+          *reinterpret_cast<float4*>(slab + i * 4) = src4[i];
         } else {
           for (int e = i * 4; e < nflt; ++e) slab[e] = src[e];
         }
@@ -189,7 +195,7 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
       for (int i = lane; i < nflt; i += kWave) slab[i] = src[i];
     }
     __syncthreads();
-    my_sh = slab + lane * S3;
+    my_sh = slab + gl * S3;
   } else {
     my_sh = sh + sg * (size_t)S3;
   }
@@ -197,7 +203,7 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
   const float* mp = means + sg * 3;
   const float m0x = mp[0], m0y = mp[1], m0z = mp[2];
 
-  for (int j = 0; j < vps; ++j) {
+  for (int j = part; j < vps; j += parts) {
     const bool vis = j < 32 ? ((vis_bits >> j) & 1u) != 0u
                             : (active && radii[(size_t)(s * vps + j) * G + g] > 0);
     if (!vis) continue;
@@ -213,8 +219,8 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
     sh_basis(DEG, dx, dy, dz, b);
     float rgb[3];
     uint32_t clamp_bits = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {      // not unrolled: 25 LDS operands live at a time, not 75
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < NB; ++k) acc = acc + b[k] * my_sh[gk3 ? k * 3 + c : c * K + k];
@@ -241,11 +247,12 @@ void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const 
   // LDS staging needs an odd float stride per Gaussian (K = 1, 9, 25), at most 75
   const bool lds = ((d.sh_coeffs * 3) & 1) && d.sh_coeffs * 3 <= 75;
   dim3 grid((d.n_gaussians + kWave - 1) / kWave, d.n_scenes), block(kWave);
+  dim3 grid32((d.n_gaussians + 31) / 32, d.n_scenes);
 #define PS_LAUNCH(DEG)                                                                        \
   do {                                                                                        \
     if (lds)                                                                                  \
-      hipLaunchKernelGGL((color_forward_kernel<DEG, true>), grid, block, 0, st, d, means, sh, \
-                         view_params, radii, records);                                        \
+      hipLaunchKernelGGL((color_forward_kernel<DEG, true>), grid32, block, 0, st, d, means,   \
+                         sh, view_params, radii, records);                                    \
     else                                                                                      \
       hipLaunchKernelGGL((color_forward_kernel<DEG, false>), grid, block, 0, st, d, means,    \
                          sh, view_params, radii, records);                                    \
