@@ -212,27 +212,14 @@ color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
   const int S3 = K * 3;
   const bool gk3 = d.sh_layout == PS_SH_GK3;
 
-  __shared__ float slab[LDS_SH ? kWave * 75 : 1];
+  __shared__ __attribute__((aligned(16))) float slab[LDS_SH ? kWave * 75 : 4];
   const size_t g0 = (size_t)s * G + (size_t)blockIdx.x * kWave;
   const int rem = G - (int)(blockIdx.x * kWave);
   const int nflt = (rem < kWave ? rem : kWave) * S3;
   float* my_slab = slab + (LDS_SH ? lane * S3 : 0);
   const float* my_sh;
   if (LDS_SH) {
-    const float* src = sh + g0 * (size_t)S3;
-    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
-      const float4* src4 = reinterpret_cast<const float4*>(src);
-      for (int i = lane; i * 4 < nflt; i += kWave) {
-        if (i * 4 + 3 < nflt) {
-          const float4 x = src4[i];
-          slab[i * 4] = x.x; slab[i * 4 + 1] = x.y; slab[i * 4 + 2] = x.z; slab[i * 4 + 3] = x.w;
-        } else {
-          for (int e = i * 4; e < nflt; ++e) slab[e] = src[e];
-        }
-      }
-    } else {
-      for (int i = lane; i < nflt; i += kWave) slab[i] = src[i];
-    }
+    stage_slab<(kWave * 75 + 255) / 256>(sh + g0 * (size_t)S3, slab, nflt, lane);
     __syncthreads();
     my_sh = my_slab;
   } else {

@@ -178,6 +178,32 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// global -> LDS copy of nflt floats by one wave.  All 16-byte loads are issued before the
+// first LDS store: a load/store-per-iteration loop serialises one memory latency per
+// iteration (this was 10-19 round trips per wave in the SH colour kernels).
+template <int MAXV4>
+__device__ __forceinline__ void stage_slab(const float* __restrict__ src, float* slab, int nflt,
+                                           int lane) {
+  if ((reinterpret_cast<size_t>(src) & 15) == 0 && nflt <= MAXV4 * kWave * 4) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    const int n4 = nflt >> 2;
+    float4 r[MAXV4];
+#pragma unroll
+    for (int u = 0; u < MAXV4; ++u) {
+      const int i = lane + u * kWave;
+      r[u] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < MAXV4; ++u) {
+      const int i = lane + u * kWave;
+      if (i < n4) *reinterpret_cast<float4*>(slab + i * 4) = r[u];
+    }
+    for (int e = n4 * 4 + lane; e < nflt; e += kWave) slab[e] = src[e];
+  } else {
+    for (int i = lane; i < nflt; i += kWave) slab[i] = src[i];
+  }
+}
+
 // rect packed as uint2: .x = xmin | ymin << 16, .y = xmax | ymax << 16 (in tiles)
 __device__ __forceinline__ bool rect_covers(uint2 r, uint32_t tx, uint32_t ty) {
   const uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu, ymax = r.y >> 16;

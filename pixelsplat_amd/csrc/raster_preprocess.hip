@@ -181,19 +181,7 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
     const size_t g0 = (size_t)s * G + (size_t)blockIdx.x * GPW;
     const int rem = G - (int)(blockIdx.x * GPW);
     const int nflt = (rem < GPW ? rem : GPW) * S3;
-    const float* src = sh + g0 * (size_t)S3;
-    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
-      const float4* src4 = reinterpret_cast<const float4*>(src);
-      for (int i = lane; i * 4 < nflt; i += kWave) {
-        if (i * 4 + 3 < nflt) {
-          *reinterpret_cast<float4*>(slab + i * 4) = src4[i];
-        } else {
-          for (int e = i * 4; e < nflt; ++e) slab[e] = src[e];
-        }
-      }
-    } else {
-      for (int i = lane; i < nflt; i += kWave) slab[i] = src[i];
-    }
+    stage_slab<(GPW * 75 + 255) / 256>(sh + g0 * (size_t)S3, slab, nflt, lane);
     __syncthreads();
     my_sh = slab + gl * S3;
   } else {
