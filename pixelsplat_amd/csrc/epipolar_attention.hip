@@ -602,7 +602,7 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
 // tools/lds_atomic_microbench.hip) against ~10 clocks for a plain ds_read/add/ds_write.
 // So the scatter is turned into an owner-computes pass with NO atomics:
 //   * one wave owns a TS x TS pixel tile of one source image, all channels, in LDS
-//     ((TS*TS + 1) * c floats); lanes <-> channels, so one LDS read-modify-write touches 64
+//     (TS*TS pixels * c floats + dummy slots); lanes <-> channels, so one LDS read-modify-write touches 64
 //     distinct addresses and a wave is the only writer of its tile;
 //   * the wave culls the rays of the casting views against its tile with a packed pixel
 //     bounding box of each ray's samples (64 rays per test, one ballot), then, for a hit,
@@ -661,7 +661,7 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
                       const uint32_t* __restrict__ boxes, const float* __restrict__ attn,
                       const float* __restrict__ ds, const float* __restrict__ dfbar,
                       const float* __restrict__ qt, float* __restrict__ dfmap) {
-  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][(TS*TS + 1)][c]
+  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][TS*TS pixels + dummy][c]
   using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
   const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
@@ -681,13 +681,14 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
   const int c0 = lane * CPL;
   const bool lane_c = c0 < dm.c;
   const int cl = lane_c ? c0 : 0;
-  float* tile = tiles + (size_t)wv * (TS * TS + 1) * dm.c;
-  for (int i = lane; i < (TS * TS + 1) * dm.c; i += kWave) tile[i] = 0.f;
+  const int tile_floats = TS * TS * dm.c + max(dm.c, kWave * CPL);   // + dummy slots
+  float* tile = tiles + (size_t)wv * tile_floats;
+  for (int i = lane; i < tile_floats; i += kWave) tile[i] = 0.f;
   wave_lds_sync();
 
   // per-wave list of the rays whose box overlaps the tile (uint16 ray index inside the
   // current super-chunk of kDfChunk rays), behind the tile copies
-  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * (TS * TS + 1) * dm.c) +
+  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * tile_floats) +
                    (size_t)wv * (kDfChunk / kDfWaves);
   const int ngroups = (dm.s + kWave - 1) / kWave;                // 1 when s <= 64
 
@@ -773,37 +774,39 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
           any |= in;
         }
         uint64_t toks = __ballot(any);
-        if (lane_c) {                        // readlane ignores EXEC; idle channel lanes sit out
-          while (toks) {
-            const int tl = __builtin_ctzll(toks);
-            toks &= toks - 1;
-            float df[CPL];
+        // Every lane runs this loop: the token lanes' records are read with v_readlane, and a
+        // value whose only use sits inside a divergent branch may be computed only for the
+        // lanes that take it.  Lanes past the last channel work on a private dummy slot.
+        while (toks) {
+          const int tl = __builtin_ctzll(toks);
+          toks &= toks - 1;
+          float df[CPL];
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) df[i] = 0.f;
+          for (int i = 0; i < CPL; ++i) df[i] = 0.f;
 #pragma unroll
-            for (int hh = 0; hh < kMaxHeads; ++hh) {
-              if (hh < H) {
-                const float a = lane_bcast(cur.av[hh], tl), d = lane_bcast(cur.dv[hh], tl);
+          for (int hh = 0; hh < kMaxHeads; ++hh) {
+            if (hh < H) {
+              const float a = lane_bcast(cur.av[hh], tl), d = lane_bcast(cur.dv[hh], tl);
 #pragma unroll
-                for (int i = 0; i < CPL; ++i)
-                  df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
-              }
+              for (int i = 0; i < CPL; ++i)
+                df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
             }
-            // four distinct pixels (or the all-zero dummy): reads first, then the writes
-            V* dst[4]; V val[4];
+          }
+          // four distinct pixels (or the dummy): reads first, then the writes
+          V* dst[4]; V val[4];
 #pragma unroll
-            for (int cr = 0; cr < 4; ++cr) {
-              dst[cr] = reinterpret_cast<V*>(tile + lane_bcast_i(off[cr], tl) + c0);
-              val[cr] = *dst[cr];
-            }
+          for (int cr = 0; cr < 4; ++cr) {
+            const int o = lane_bcast_i(off[cr], tl);
+            dst[cr] = reinterpret_cast<V*>(tile + (lane_c ? o : TS * TS * dm.c) + c0);
+            val[cr] = *dst[cr];
+          }
 #pragma unroll
-            for (int cr = 0; cr < 4; ++cr) {
-              const float wgt = lane_bcast(wt[cr], tl);
-              float* f = reinterpret_cast<float*>(&val[cr]);
+          for (int cr = 0; cr < 4; ++cr) {
+            const float wgt = lane_bcast(wt[cr], tl);
+            float* f = reinterpret_cast<float*>(&val[cr]);
 #pragma unroll
-              for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[i], f[i]);
-              *dst[cr] = val[cr];
-            }
+            for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[i], f[i]);
+            *dst[cr] = val[cr];
           }
         }
         cur = nxt;
@@ -821,7 +824,7 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < kDfWaves; ++k)
-      acc += tiles[((size_t)k * (TS * TS + 1) + py * TS + px) * dm.c + ch];
+      acc += tiles[(size_t)k * tile_floats + (py * TS + px) * dm.c + ch];
     out[((size_t)(ty0 + py) * dm.w + tx0 + px) * dm.c + ch] = acc;
   }
 }
@@ -915,8 +918,9 @@ int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint
     const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
     const int n_work = dm.b * dm.v * tiles;
     dim3 g2((unsigned)((n_work + 7) / 8 * 8)), b2(kDfWaves * kWave);
-    const size_t sm2 = (size_t)kDfWaves * (TS * TS + 1) * dm.c * sizeof(float) +
-                       kDfChunk * sizeof(uint16_t);
+    const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
+    const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
+    const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
 #define PS_DF(CPL)                                                                              \
   hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, n_work, xy, boxes,  \
                      attn,                                                                      \

@@ -126,14 +126,21 @@ def test_fused_attention_vs_reference_golden(gpu_device, name):
     assert ((y + x).cpu() - g["attn_out"]).abs().max() < 5e-3
 
 
-def test_fused_attention_vs_oracle_and_autograd(gpu_device):
+@pytest.mark.parametrize("dims", [
+    (2, 3, 16, 6, 8, 4, 2, 8),       # view embeddings, T = 8
+    (1, 2, 64, 5, 7, 13, 3, 16),     # channel class 64, T = 13 (chunk tail), 3 heads, odd sizes
+    (1, 2, 256, 4, 4, 9, 4, 8),      # channel class 256
+    (1, 3, 36, 3, 5, 40, 1, 12),     # c = 36 (class 64 with idle lanes), T = 80 (> 64), 1 head
+    (1, 2, 128, 9, 9, 32, 4, 32),    # the paper's per-ray shape
+])
+def test_fused_attention_vs_oracle_and_autograd(gpu_device, dims):
     """Same rel_disparity on both sides (so the PE noise amplification drops out): forward to
     1e-5 and every gradient (features, q path, depth-encoding weights, to_kv / to_out)
     against torch autograd through the oracle's unfused restatement."""
     from pixelsplat_amd.epipolar import fused_cross_attention, sample_geometry
 
     torch.manual_seed(0)
-    b, v, c, h, w, s, heads, dh = 2, 3, 16, 6, 8, 4, 2, 8
+    b, v, c, h, w, s, heads, dh = dims
     ctx = _cams(b, v, 5)
     feat = torch.randn(b, v, c, h, w)
     dev = gpu_device
@@ -146,6 +153,8 @@ def test_fused_attention_vs_oracle_and_autograd(gpu_device):
              w_out=torch.randn(c, inner) * 0.3, b_out=torch.randn(c) * 0.1,
              depth_w=torch.randn(c, 20) * 0.3, depth_b=torch.randn(c) * 0.1,
              view_emb=torch.randn(v - 1, c) * 0.3)
+    if c == 128:       # the 2-view configs have no view embedding (epipolar_transformer.py:126)
+        del P["view_emb"]
     x = torch.randn(b * v * h * w, 1, c)
     gout = torch.randn(b * v * h * w, 1, c)
 
@@ -165,7 +174,9 @@ def test_fused_attention_vs_oracle_and_autograd(gpu_device):
             sampled = sampled * geo.overlaps.cpu()[..., None, None]
             enc = E.positional_encoding(geo.rel_disparity.cpu(), 10) @ leaves["depth_w"].T \
                 + leaves["depth_b"]
-            kv = sampled + enc + leaves["view_emb"][None, None, :, None, None, :]
+            kv = sampled + enc
+            if "view_emb" in leaves:
+                kv = kv + leaves["view_emb"][None, None, :, None, None, :]
             z = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, s * (v - 1), c)
             q = xx @ leaves["w_q"].T
             k_, v_ = (z @ leaves["w_kv"].T).chunk(2, dim=-1)
