@@ -222,6 +222,11 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
  *                  heads <= 4, T <= 128, h, w <= 255 for the gradient. */
 typedef struct PsEpipolarDesc {
   int32_t b, v, h, w, s, c, heads, octaves;
+  /* row strides in floats (0 = contiguous): qt/dqt, u/du, e/de, fbar/dfbar, pbar/dpbar,
+   * abar/dabar.  With ld_q = ld_u = ld_e the three inputs are column blocks of ONE matrix
+   * (one GEMM produces them), likewise the outputs.  ld_q and ld_f must be multiples of 4
+   * and the qt / fbar / dfbar pointers 16-byte aligned. */
+  int32_t ld_q, ld_u, ld_e, ld_f, ld_p, ld_a;
 } PsEpipolarDesc;
 int ps_epipolar_gather(const PsEpipolarDesc* desc, const float* fmap, const float* xy_sample,
                        const uint8_t* flags, float* features /*[b][v][v-1][h*w][s][c]*/,

@@ -37,7 +37,8 @@ class PsRasterStateLayout(C.Structure):
 
 
 class PsEpipolarDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("b", "v", "h", "w", "s", "c", "heads", "octaves")]
+    _fields_ = [(n, C.c_int32) for n in ("b", "v", "h", "w", "s", "c", "heads", "octaves",
+                                         "ld_q", "ld_u", "ld_e", "ld_f", "ld_p", "ld_a")]
 
 
 # every symbol include/pixelsplat_hip.h declares

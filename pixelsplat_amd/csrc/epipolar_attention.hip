@@ -458,8 +458,9 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   const size_t rh = (size_t)k.ray * k.H;
   stage_records(dm, k, lane, xy, flags, rd);
   QueryRegs Q;
-  load_query(dm, k, lane, qt + rh * dm.c, u + rh * k.P, Q);
-  const float* erow = e ? e + rh * k.ovn : nullptr;
+  const size_t ray = (size_t)k.ray;
+  load_query(dm, k, lane, qt + ray * dm.ld_q, u + ray * dm.ld_u, Q);
+  const float* erow = e ? e + ray * dm.ld_e : nullptr;
 
   ContextRegs<CK> A;
   A.clear();
@@ -507,10 +508,10 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     const float inv = 1.0f / l_run[hh];
     if (c0 < dm.c) {
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) fbar[(rh + hh) * dm.c + c0 + i] = A.f[hh][i] * inv;
+      for (int i = 0; i < CPL; ++i) fbar[ray * dm.ld_f + hh * dm.c + c0 + i] = A.f[hh][i] * inv;
     }
-    if (lane < k.P) pbar[(rh + hh) * k.P + lane] = A.p[hh] * inv;
-    if (e != nullptr && lane < k.ovn) abar[(rh + hh) * k.ovn + lane] = A.o[hh] * inv;
+    if (lane < k.P) pbar[ray * dm.ld_p + hh * k.P + lane] = A.p[hh] * inv;
+    if (e != nullptr && lane < k.ovn) abar[ray * dm.ld_a + hh * k.ovn + lane] = A.o[hh] * inv;
     for (int t = lane; t < k.T; t += kWave)
       attn[(rh + hh) * k.T + t] = __expf(k.scS[hh * k.T + t] - m_run[hh]) * inv;
   }
@@ -542,8 +543,9 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   const size_t rh = (size_t)k.ray * k.H;
   stage_records(dm, k, lane, xy, flags, rd);
   QueryRegs Q;
-  load_query(dm, k, lane, dfbar + rh * dm.c, dpbar + rh * k.P, Q);
-  const float* erow = dabar ? dabar + rh * k.ovn : nullptr;
+  const size_t ray = (size_t)k.ray;
+  load_query(dm, k, lane, dfbar + ray * dm.ld_f, dpbar + ray * dm.ld_p, Q);
+  const float* erow = dabar ? dabar + ray * dm.ld_a : nullptr;
 
   ContextRegs<CK> A;
   A.clear();
@@ -576,15 +578,17 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
     if (c0 < dm.c) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i)
-        dqt[(rh + hh) * dm.c + c0 + i] =
-            scale * (A.f[hh][i] - d * fbar[(rh + hh) * dm.c + c0 + i]);
+        dqt[ray * dm.ld_q + hh * dm.c + c0 + i] =
+            scale * (A.f[hh][i] - d * fbar[ray * dm.ld_f + hh * dm.c + c0 + i]);
     }
-    if (lane < k.P) du[(rh + hh) * k.P + lane] = scale * (A.p[hh] - d * pbar[(rh + hh) * k.P + lane]);
+    if (lane < k.P)
+      du[ray * dm.ld_u + hh * k.P + lane] =
+          scale * (A.p[hh] - d * pbar[ray * dm.ld_p + hh * k.P + lane]);
     if (lane < k.ovn) {
       // abar is only produced when the view embedding exists; otherwise it is the softmax mass
       // of the single other view, i.e. one
-      const float ab = abar ? abar[(rh + hh) * k.ovn + lane] : 1.0f;
-      de[(rh + hh) * k.ovn + lane] = scale * (A.o[hh] - d * ab);
+      const float ab = abar ? abar[ray * dm.ld_a + hh * k.ovn + lane] : 1.0f;
+      de[ray * dm.ld_e + hh * k.ovn + lane] = scale * (A.o[hh] - d * ab);
     }
     for (int t = lane; t < k.T; t += kWave)
       ds_out[(rh + hh) * k.T + t] =
@@ -750,8 +754,9 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
           const size_t rowh = ray * H + (hh < H ? hh : 0);
           x.av[hh] = attn[rowh * T + si * ovn + ov];
           x.dv[hh] = ds[rowh * T + si * ovn + ov];
-          load_cpl<CPL>(dfbar + rowh * dm.c + cl, x.gq[hh]);
-          load_cpl<CPL>(qt + rowh * dm.c + cl, x.qq[hh]);
+          const int hs = hh < H ? hh : 0;
+          load_cpl<CPL>(dfbar + ray * dm.ld_f + hs * dm.c + cl, x.gq[hh]);
+          load_cpl<CPL>(qt + ray * dm.ld_q + hs * dm.c + cl, x.qq[hh]);
         }
       };
       const int n_items = count * ngroups;
@@ -840,7 +845,8 @@ static size_t attn_smem(const AttnDims& dm) {
 static bool attn_dims_ok(const AttnDims& dm) {
   return attn_smem(dm) <= 160 * 1024 && dm.heads >= 1 && dm.heads <= kMaxHeads &&
          dm.s * (dm.v - 1) <= 128 && dm.s * (dm.v - 1) >= 1 && 2 * dm.octaves <= 8 * kUPL &&
-         dm.octaves >= 1 && dm.c % 4 == 0 && dm.c >= 4 && dm.c <= 256 &&
+         dm.octaves >= 1 && dm.c % 4 == 0 && dm.c >= 4 && dm.c <= 256 && dm.ld_q % 4 == 0 &&
+         dm.ld_f % 4 == 0 &&
          (size_t)dm.b * dm.v * dm.h * dm.w < (size_t)1 << 30;
 }
 

@@ -262,7 +262,11 @@ bool epi_ok(const PsEpipolarDesc* d) {
          d->heads > 0 && d->octaves > 0;
 }
 AttnDims to_dims(const PsEpipolarDesc* d) {
-  return AttnDims{d->b, d->v, d->h, d->w, d->s, d->c, d->heads, d->octaves};
+  const int P = 2 * d->octaves, ov = d->v - 1, H = d->heads;
+  auto ld = [](int given, int dflt) { return given > 0 ? given : dflt; };
+  return AttnDims{d->b, d->v, d->h, d->w, d->s, d->c, d->heads, d->octaves,
+                  ld(d->ld_q, H * d->c), ld(d->ld_u, H * P), ld(d->ld_e, H * ov),
+                  ld(d->ld_f, H * d->c), ld(d->ld_p, H * P), ld(d->ld_a, H * ov)};
 }
 }  // namespace
 

@@ -129,57 +129,77 @@ class _RayLinear(torch.autograd.Function):
         return dx, dw, db
 
 
+def _pad4(n: int) -> int:
+    return (n + 3) & ~3
+
+
 class _FusedEpipolarAttention(torch.autograd.Function):
-    """(fmap, q~, u, e) -> (fbar, pbar, abar, attn); see csrc/epipolar_attention.hip."""
+    """(fmap, [q~ | u | e]) -> ([fbar | pbar | abar], attn); see csrc/epipolar_attention.hip.
+
+    Inputs and outputs of the kernel are column blocks of ONE row-major matrix each (block
+    widths padded to multiples of 4 floats), so one GEMM feeds the kernel and one consumes it.
+    """
 
     @staticmethod
-    def forward(ctx, dims, scale, fmap, xy, flags, rd, qt, u, e):
+    def widths(dims, has_e):
+        b, v, h, w, s, c, heads, octaves = dims
+        return heads * c, _pad4(heads * 2 * octaves), (_pad4(heads * (v - 1)) if has_e else 0)
+
+    @staticmethod
+    def forward(ctx, dims, scale, has_e, fmap, xy, flags, rd, qin):
         lib = _lib.load()
         b, v, h, w, s, c, heads, octaves = dims
+        R, T = b * v * h * w, s * (v - 1)
+        wq, wu, we = _FusedEpipolarAttention.widths(dims, has_e)
+        ld = wq + wu + we
+        fmap, qin = fmap.contiguous(), qin.contiguous()
+        assert qin.shape == (R, ld)
         d = _desc(*dims)
-        R, T, P, ov = b * v * h * w, s * (v - 1), 2 * octaves, v - 1
-        dev = fmap.device
-        fmap, qt, u = fmap.contiguous(), qt.contiguous(), u.contiguous()
-        e = None if e is None else e.contiguous()
-        f32 = dict(dtype=torch.float32, device=dev)
-        fbar = torch.empty((R, heads, c), **f32)
-        pbar = torch.empty((R, heads, P), **f32)
-        abar = torch.empty((R, heads, ov), **f32)
-        attn = torch.empty((R, heads, T), **f32)
+        d.ld_q = d.ld_u = d.ld_e = d.ld_f = d.ld_p = d.ld_a = ld
+        padded = wu != heads * 2 * octaves or (has_e and we != heads * (v - 1))
+        out = (torch.zeros if padded else torch.empty)((R, ld), dtype=torch.float32,
+                                                       device=fmap.device)
+        attn = torch.empty((R, heads, T), dtype=torch.float32, device=fmap.device)
+        col = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
         _lib.check(lib.ps_epipolar_attention_forward(
-            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), _p(qt), _p(u), _p(e),
-            C.c_float(scale), _p(fbar), _p(pbar), _p(abar), _p(attn), _stream()),
-            "ps_epipolar_attention_forward")
-        ctx.dims, ctx.scale, ctx.has_e = dims, scale, e is not None
-        ctx.save_for_backward(fmap, xy, flags, rd, qt, attn, fbar, pbar, abar)
+            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), col(qin, 0), col(qin, wq),
+            col(qin, wq + wu) if has_e else None, C.c_float(scale), col(out, 0), col(out, wq),
+            col(out, wq + wu), _p(attn), _stream()), "ps_epipolar_attention_forward")
+        ctx.dims, ctx.scale, ctx.has_e, ctx.padded = dims, scale, has_e, padded
+        ctx.save_for_backward(fmap, xy, flags, rd, qin, attn, out)
         ctx.mark_non_differentiable(attn)
-        return fbar, pbar, abar, attn
+        return out, attn
 
     @staticmethod
-    def backward(ctx, dfbar, dpbar, dabar, _dattn):
+    def backward(ctx, dout, _dattn):
         lib = _lib.load()
-        fmap, xy, flags, rd, qt, attn, fbar, pbar, abar = ctx.saved_tensors
+        fmap, xy, flags, rd, qin, attn, out = ctx.saved_tensors
         b, v, h, w, s, c, heads, octaves = ctx.dims
+        R, T, ov = b * v * h * w, s * (v - 1), v - 1
+        wq, wu, we = _FusedEpipolarAttention.widths(ctx.dims, ctx.has_e)
+        ld = wq + wu + we
         d = _desc(*ctx.dims)
-        R, T, P, ov = b * v * h * w, s * (v - 1), 2 * octaves, v - 1
+        d.ld_q = d.ld_u = d.ld_e = d.ld_f = d.ld_p = d.ld_a = ld
+        dout = dout.contiguous()
         f32 = dict(dtype=torch.float32, device=fmap.device)
-        dqt = torch.empty((R, heads, c), **f32)
-        du = torch.empty((R, heads, P), **f32)
-        de = torch.empty((R, heads, ov), **f32)
+        dqin = (torch.zeros if ctx.padded else torch.empty)((R, ld), **f32)
+        de_scratch = None if ctx.has_e else torch.empty((R, heads * ov), **f32)
         ds = torch.empty((R, heads, T), **f32)
         dfmap = boxes = None
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[3]:
             dfmap = torch.empty_like(fmap)
             boxes = torch.empty((R * ov,), dtype=torch.int32, device=fmap.device)
+        col = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
+        if not ctx.has_e:           # de is still written (unused): give it its own buffer
+            d.ld_e = heads * ov
         _lib.check(lib.ps_epipolar_attention_backward(
-            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), _p(qt), _p(attn), _p(fbar), _p(pbar),
-            _p(abar if ctx.has_e else None),
-            _p(dfbar.contiguous()), _p(dpbar.contiguous()),
-            _p(dabar.contiguous() if ctx.has_e else None),
-            C.c_float(ctx.scale), _p(dqt), _p(du), _p(de), _p(ds), _p(dfmap), _p(boxes),
-            _stream()),
-            "ps_epipolar_attention_backward")
-        return (None, None, dfmap, None, None, None, dqt, du, de if ctx.has_e else None)
+            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), col(qin, 0), _p(attn), col(out, 0),
+            col(out, wq), col(out, wq + wu) if ctx.has_e else None,
+            col(dout, 0), col(dout, wq), col(dout, wq + wu) if ctx.has_e else None,
+            C.c_float(ctx.scale), col(dqin, 0), col(dqin, wq),
+            col(dqin, wq + wu) if ctx.has_e else _p(de_scratch), _p(ds), _p(dfmap), _p(boxes),
+            _stream()), "ps_epipolar_attention_backward")
+        return (None, None, None, dfmap, None, None, None, dqin)
 
 
 def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *, w_q: Tensor,
@@ -208,30 +228,32 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     w_v = w_kv[inner:].reshape(heads, dh, c)
     m_q = torch.einsum("hkc,hkd->hcd", w_k, w_q.reshape(heads, dh, d_in))       # [H, c, d]
     n_o = torch.einsum("ohk,hkc->ohc", w_out.reshape(d_out, heads, dh), w_v)    # [o, H, c]
-    w_in = [m_q.reshape(heads * c, d_in),
-            torch.einsum("cp,hcd->hpd", depth_w, m_q).reshape(heads * P, d_in)]
-    w_o = [n_o.reshape(d_out, heads * c),
-           torch.einsum("ohc,cp->ohp", n_o, depth_w).reshape(d_out, heads * P)]
-    if view_emb is not None:
+    has_e = view_emb is not None
+    dims = (b, v, h, w, s, c, heads, octaves)
+    wq, wu, we = _FusedEpipolarAttention.widths(dims, has_e)
+
+    rows_in = [m_q.reshape(heads * c, d_in),
+               torch.einsum("cp,hcd->hpd", depth_w, m_q).reshape(heads * P, d_in)]
+    cols_out = [n_o.reshape(d_out, heads * c),
+                torch.einsum("ohc,cp->ohp", n_o, depth_w).reshape(d_out, heads * P)]
+    widths = [wq, wu]
+    if has_e:
         ovn = view_emb.shape[0]
-        w_in.append(torch.einsum("oc,hcd->hod", view_emb, m_q).reshape(heads * ovn, d_in))
-        w_o.append(torch.einsum("ohc,vc->ohv", n_o, view_emb).reshape(d_out, heads * ovn))
+        rows_in.append(torch.einsum("oc,hcd->hod", view_emb, m_q).reshape(heads * ovn, d_in))
+        cols_out.append(torch.einsum("ohc,vc->ohv", n_o, view_emb).reshape(d_out, heads * ovn))
+        widths.append(we)
+    pad_r = lambda m, wd: m if m.shape[0] == wd else torch.nn.functional.pad(m, (0, 0, 0, wd - m.shape[0]))
+    pad_c = lambda m, wd: m if m.shape[1] == wd else torch.nn.functional.pad(m, (0, wd - m.shape[1]))
+    w_in = torch.cat([pad_r(m, wd) for m, wd in zip(rows_in, widths)], 0)       # [ld, d]
+    w_o = torch.cat([pad_c(m, wd) for m, wd in zip(cols_out, widths)], 1)       # [d_out, ld]
     bias = n_o.sum(1) @ depth_b          # softmax weights sum to one
     if b_out is not None:
         bias = bias + b_out
-    x2 = x.reshape(R, d_in)
-    qt = _RayLinear.apply(x2, w_in[0], None).reshape(R, heads, c)
-    u = _RayLinear.apply(x2, w_in[1], None).reshape(R, heads, P)
-    e = None if view_emb is None else (x2 @ w_in[2].T).reshape(R, heads, -1)
-    dims = (b, v, h, w, s, c, heads, octaves)
-    fbar, pbar, abar, attn = _FusedEpipolarAttention.apply(
-        dims, float(dh) ** -0.5, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample, geo.flags,
-        geo.rel_disparity, qt, u, e)
-    out = _RayLinear.apply(fbar.reshape(R, heads * c), w_o[0], bias)
-    out = out + _RayLinear.apply(pbar.reshape(R, heads * P), w_o[1], None)
-    if view_emb is not None:
-        out = torch.addmm(out, abar.reshape(R, -1), w_o[2].T)
-    out = out.reshape(R, 1, d_out)
+    qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None)                      # [q~ | u | e]
+    fused, attn = _FusedEpipolarAttention.apply(
+        dims, float(dh) ** -0.5, has_e, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample,
+        geo.flags, geo.rel_disparity, qin)
+    out = _RayLinear.apply(fused, w_o, bias).reshape(R, 1, d_out)
     if return_attn:
         return out, attn.reshape(R, heads, 1, -1)
     return out
