@@ -46,6 +46,27 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic(group):
+    """HBM-side bytes per launch of the kernel behind a profile group, from the committed
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (tools/pmc_summary.py; counters cannot be
+    read from inside the process).  None when no summary is committed or the group is not a
+    single kernel."""
+    import glob
+    key = {"tiles_backward": "tiles_backward_kernel", "tiles_forward": "tiles_forward_kernel",
+           "epipolar_attention_forward": "epipolar_attn_forward_kernel",
+           "epipolar_attention_backward": "epipolar_attn_backward_kernel",
+           "epipolar_feature_grad": "epipolar_dfmap_kernel"}.get(group)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if key is None or not files:
+        return None, None
+    with open(files[-1]) as f:
+        kernels = json.load(f)["kernels"]
+    for name, v in kernels.items():
+        if key in name:
+            return float(v["bytes"]), os.path.basename(files[-1])
+    return None, None
+
+
 def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     """The oracle (CPU port of the same algorithm) timed on the host cores over a bounded
     sample of the same workload: the first `n_views` views of the batch (scene-major),
@@ -253,6 +274,7 @@ def main():
         dom = max(alg, key=lambda k: groups[k][0])
         dom_ms = groups[dom][0]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             "metric": "rendered views/sec (fwd+bwd)", "value": round(value, 2), "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,7 +293,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_kernel_ms": round(dom_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_kernel_ms": round(dom_ms, 4),
                 "algorithmic_bytes_per_launch": alg[dom],
             },
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},
