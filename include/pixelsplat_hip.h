@@ -246,6 +246,12 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap
                                    float* dqt, float* du, float* de, float* ds, float* dfmap,
                                    uint32_t* ray_boxes, void* stream);
 
+/* w2c[i] = c2w[i]^-1 (4x4) and k_inv[i] = k[i]^-1 (3x3) for n cameras, one launch, no host
+ * sync (replaces the sampler's torch.linalg.inv calls: src/geometry/epipolar_lines.py:167,
+ * src/geometry/projection.py:84). */
+int ps_invert_cameras(int32_t n, const float* c2w, const float* k, float* w2c, float* k_inv,
+                      void* stream);
+
 /* C[m][n] = sum_k A[k][m] B[k][n] in fp32 (v_mfma_f32_32x32x2_f32), split over k with a
  * fixed-order reduction: the weight gradients of the folded attention matrices
  * (dW = dY^T X over all rays; autograd of the Linear layers at attention.py:36-45,

@@ -322,6 +322,13 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
   return check_launch();
 }
 
+int ps_invert_cameras(int32_t n, const float* c2w, const float* k, float* w2c, float* k_inv,
+                      void* stream) {
+  if (n <= 0 || !c2w || !k || !w2c || !k_inv) return PS_ERR_BAD_ARG;
+  launch_camera_inverse(n, c2w, k, w2c, k_inv, (hipStream_t)stream);
+  return check_launch();
+}
+
 size_t ps_gemm_tn_workspace_bytes(int32_t m, int32_t n, int32_t k) {
   return (m > 0 && n > 0 && k > 0) ? gemm_tn_workspace_bytes(m, n, k) : 0;
 }

@@ -9,8 +9,9 @@
 
 namespace ps {
 
-__device__ inline bool invert4(const float* m, float* inv) {  // general 4x4, cofactors
-  float a[16];
+template <typename T>
+__device__ inline bool invert4(const T* m, T* inv) {  // general 4x4, cofactors
+  T a[16];
   a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
          m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
   a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
@@ -43,18 +44,19 @@ __device__ inline bool invert4(const float* m, float* inv) {  // general 4x4, co
           m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
   a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
           m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-  const float det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
-  const float id = 1.0f / det;
+  const T det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+  const T id = T(1) / det;
 #pragma unroll
   for (int i = 0; i < 16; ++i) inv[i] = a[i] * id;
-  return det != 0.0f;
+  return det != T(0);
 }
 
-__device__ inline void invert3(const float* k, float* inv) {
-  const float c00 = k[4] * k[8] - k[5] * k[7], c01 = k[5] * k[6] - k[3] * k[8],
-              c02 = k[3] * k[7] - k[4] * k[6];
-  const float det = k[0] * c00 + k[1] * c01 + k[2] * c02;
-  const float id = 1.0f / det;
+template <typename T>
+__device__ inline void invert3(const T* k, T* inv) {
+  const T c00 = k[4] * k[8] - k[5] * k[7], c01 = k[5] * k[6] - k[3] * k[8],
+          c02 = k[3] * k[7] - k[4] * k[6];
+  const T det = k[0] * c00 + k[1] * c01 + k[2] * c02;
+  const T id = T(1) / det;
   inv[0] = c00 * id; inv[1] = (k[2] * k[7] - k[1] * k[8]) * id; inv[2] = (k[1] * k[5] - k[2] * k[4]) * id;
   inv[3] = c01 * id; inv[4] = (k[0] * k[8] - k[2] * k[6]) * id; inv[5] = (k[2] * k[3] - k[0] * k[5]) * id;
   inv[6] = c02 * id; inv[7] = (k[1] * k[6] - k[0] * k[7]) * id; inv[8] = (k[0] * k[4] - k[1] * k[3]) * id;
@@ -130,6 +132,34 @@ void launch_camera_setup(int n_views, const float* extrinsics, const float* intr
                          int scale_invariant, float* view_params, hipStream_t st) {
   hipLaunchKernelGGL(camera_setup_kernel, dim3((n_views + 63) / 64), dim3(64), 0, st, n_views,
                      extrinsics, intrinsics, near, far, bg, scale_invariant, view_params);
+}
+
+// w2c = c2w^-1 and K^-1 for n cameras in one launch (the sampler's torch.linalg.inv calls:
+// /root/reference/src/geometry/epipolar_lines.py:167, src/geometry/projection.py:84; torch's
+// inv also checks for singularity on the host, i.e. synchronises).  Cofactors in double,
+// rounded once.
+__global__ void camera_inverse_kernel(int n, const float* __restrict__ c2w,
+                                      const float* __restrict__ k, float* __restrict__ w2c,
+                                      float* __restrict__ k_inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double m[16], mi[16], kk[9], ki[9];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) m[j] = (double)c2w[16 * i + j];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) kk[j] = (double)k[9 * i + j];
+  invert4<double>(m, mi);
+  invert3<double>(kk, ki);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) w2c[16 * i + j] = (float)mi[j];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) k_inv[9 * i + j] = (float)ki[j];
+}
+
+void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(camera_inverse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, c2w, k, w2c,
+                     k_inv);
 }
 
 }  // namespace ps

@@ -163,6 +163,8 @@ int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint
                                  const float* qt, const float* attn, const float* dfbar,
                                  const float* ds, float* dfmap, uint32_t* boxes, hipStream_t st);
 
+void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
+                           hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
 int launch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                    float* C, float* workspace, hipStream_t st);

@@ -33,8 +33,8 @@ def sample_geometry(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: T
                     grid_hw: tuple[int, int], num_samples: int, w2c: Tensor | None = None,
                     k_inv: Tensor | None = None) -> EpipolarGeometry:
     """extrinsics [b,v,4,4] c2w, intrinsics [b,v,3,3] normalised, near/far [b,v]; rays are the
-    pixel centres of an h x w grid.  `w2c` / `k_inv` default to torch.linalg.inv on the device
-    (the reference inverts with torch too: epipolar_lines.py:167, projection.py:84)."""
+    pixel centres of an h x w grid.  `w2c` / `k_inv` default to ps_invert_cameras (the
+    reference inverts with torch.linalg.inv: epipolar_lines.py:167, projection.py:84)."""
     lib = _lib.load()
     if not extrinsics.is_cuda:
         raise RuntimeError("pixelsplat_amd.epipolar needs GPU tensors (no CPU fallback)")
@@ -44,8 +44,14 @@ def sample_geometry(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: T
     dev = extrinsics.device
     c2w = extrinsics.contiguous().float()
     k = intrinsics.contiguous().float()
-    w2c = (torch.linalg.inv(c2w) if w2c is None else w2c).contiguous().float()
-    k_inv = (torch.linalg.inv(k) if k_inv is None else k_inv).contiguous().float()
+    if w2c is None or k_inv is None:     # one launch, no host sync (torch.linalg.inv syncs)
+        w2c_d = torch.empty_like(c2w)
+        k_inv_d = torch.empty_like(k)
+        _lib.check(lib.ps_invert_cameras(C.c_int32(b * v), _p(c2w), _p(k), _p(w2c_d),
+                                         _p(k_inv_d), _stream()), "ps_invert_cameras")
+        w2c = w2c_d if w2c is None else w2c
+        k_inv = k_inv_d if k_inv is None else k_inv
+    w2c, k_inv = w2c.contiguous().float(), k_inv.contiguous().float()
     nr, fr = near.contiguous().float(), far.contiguous().float()
     f32 = dict(dtype=torch.float32, device=dev)
     origins = torch.empty((b, v, r, 3), **f32)
