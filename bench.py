@@ -190,8 +190,9 @@ def main():
     def path_a():
         geo = et.epipolar_sampler.geometry(c_ext, c_intr, c_near, c_far, (hA, wA))
         x = feat.reshape(-1, 1, d_feat)
-        for attn, _ff in et.transformer.layers:
-            x = et.fused_layer(attn, x, feat, geo) + x
+        folds = et.fold_layers()
+        for (attn, _ff), folded in zip(et.transformer.layers, folds):
+            x = et.fused_layer(attn, x, feat, geo, folded=folded) + x
         return x.square().mean()
 
     def path_b():

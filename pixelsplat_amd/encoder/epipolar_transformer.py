@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from ..epipolar import fused_cross_attention, gather_features
+from ..epipolar import fold_attention_weights, fused_cross_attention, gather_features
 from .epipolar_sampler import EpipolarSampler, EpipolarSampling
 from .transformer import Transformer
 
@@ -124,6 +124,7 @@ class EpipolarTransformer(nn.Module):
         if num_context_views is None:
             raise ValueError("num_context_views not given and the reference global cfg is absent")
         self.cfg = cfg
+        self._side_stream = None
         self.epipolar_sampler = EpipolarSampler(num_context_views, cfg.num_samples)
         if cfg.num_octaves > 0:
             self.depth_encoding = nn.Sequential(
@@ -141,20 +142,42 @@ class EpipolarTransformer(nn.Module):
         if num_context_views > 2:
             self.view_embeddings = nn.Embedding(num_context_views, d_in)
 
-    def fused_layer(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None) -> Tensor:
-        """PreNorm(Attention)(x, z=kv) (pre_norm.py:34-35, attention.py:54-70) on the HIP path;
-        `attn` is one `layer[0]` of `self.transformer.layers`, fmap is channels-last."""
+    def _layer_weights(self, attn: nn.Module, view_emb=None) -> dict:
         a = attn.fn
-        c = fmap.shape[-1]
         lin = self.depth_encoding[1]
         to_out = a.to_out[0] if isinstance(a.to_out, nn.Sequential) else None
-        return fused_cross_attention(
-            attn.norm(x), fmap, geo, w_q=a.to_q.weight, w_kv=a.to_kv.weight,
-            w_out=(to_out.weight if to_out is not None else
-                   torch.eye(c, device=x.device, dtype=x.dtype)),
-            b_out=(to_out.bias if to_out is not None else None), heads=a.heads,
-            depth_w=lin.weight, depth_b=lin.bias, octaves=self.cfg.num_octaves,
-            view_emb=view_emb)
+        c = lin.weight.shape[0]
+        return dict(w_q=a.to_q.weight, w_kv=a.to_kv.weight,
+                    w_out=(to_out.weight if to_out is not None else
+                           torch.eye(c, device=lin.weight.device, dtype=lin.weight.dtype)),
+                    b_out=(to_out.bias if to_out is not None else None), heads=a.heads,
+                    depth_w=lin.weight, depth_b=lin.bias, view_emb=view_emb)
+
+    def fold_layers(self, view_emb=None) -> list:
+        """Folded weight matrices of every cross-attention layer, computed on a side stream:
+        they depend on the parameters only, and their ~40 tiny kernels per layer (forward, and
+        again in backward -- autograd replays a node on the stream of its forward) then overlap
+        the big kernels instead of queueing between them."""
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            folds = [fold_attention_weights(**self._layer_weights(attn, view_emb))
+                     for attn, _ in self.transformer.layers]
+        main.wait_stream(side)
+        for f in folds:
+            for t in f:
+                t.record_stream(main)
+        return folds
+
+    def fused_layer(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None,
+                    folded=None) -> Tensor:
+        """PreNorm(Attention)(x, z=kv) (pre_norm.py:34-35, attention.py:54-70) on the HIP path;
+        `attn` is one `layer[0]` of `self.transformer.layers`, fmap is channels-last."""
+        return fused_cross_attention(attn.norm(x), fmap, geo, octaves=self.cfg.num_octaves,
+                                     folded=folded, **self._layer_weights(attn, view_emb))
 
     def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor, materialize_sampling: bool = False,
@@ -183,7 +206,8 @@ class EpipolarTransformer(nn.Module):
 
         x = fmap.reshape(b * v * h * w, 1, c)
         kv = None
-        for attn, ff in self.transformer.layers:
+        folds = self.fold_layers(view_emb) if features.is_cuda else [None] * len(self.transformer.layers)
+        for (attn, ff), folded in zip(self.transformer.layers, folds):
             a = attn.fn
             if len(a.attend._forward_hooks) > 0:
                 if kv is None:   # unfused formulation so the hook sees the attention weights
@@ -193,7 +217,7 @@ class EpipolarTransformer(nn.Module):
                     kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
                 y = attn(x, z=kv)
             else:
-                y = self.fused_layer(attn, x, fmap, geo, view_emb)
+                y = self.fused_layer(attn, x, fmap, geo, view_emb, folded)
             x = y + x
             x = ff(x, b=b, v=v, h=h, w=w) + x
         features = x.reshape(b, v, h, w, c).permute(0, 1, 4, 2, 3)

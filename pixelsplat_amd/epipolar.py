@@ -208,36 +208,27 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         return (None, None, None, dfmap, None, None, None, dqin)
 
 
-def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *, w_q: Tensor,
-                          w_kv: Tensor, w_out: Tensor, b_out: Tensor | None, heads: int,
-                          depth_w: Tensor, depth_b: Tensor, octaves: int,
-                          view_emb: Tensor | None = None, return_attn: bool = False):
-    """Attention(x, z=kv) of the reference (attention.py:54-70) for kv = gathered features +
-    Linear(PE(relative disparity)) [+ view embedding], without ever forming kv.
-
-    x [R, 1, d] (already layer-normed), fmap_nhwc [b, v, h, w, c]; w_q [inner, d],
-    w_kv [2*inner, c], w_out [d, inner]; depth_w [c, 2*octaves], depth_b [c];
-    view_emb [v-1, c] (already permuted) or None.  Returns [R, 1, d] (and attn [R,H,1,T])."""
-    b, v, h, w, c = fmap_nhwc.shape
-    s = geo.xy_sample.shape[-2]
-    inner = w_q.shape[0]
+def fold_attention_weights(*, w_q: Tensor, w_kv: Tensor, w_out: Tensor, b_out: Tensor | None,
+                           heads: int, depth_w: Tensor, depth_b: Tensor,
+                           view_emb: Tensor | None = None):
+    """Every linear map on either side of the kernel folded into ONE weight matrix per side
+    (tiny [H, c, d] products, differentiable, recomputed each call):
+        q~_h = (W_k,h^T W_q,h) x,  u_h = W_d^T q~_h,  e_h = E q~_h          -> W_in  [ld, d]
+        y = sum_h (W_o,h W_v,h)(fbar_h + W_d pbar_h + E^T abar_h + b_d) + b_o -> W_o [d_out, ld], bias
+    Depends on the weights only, so a caller may run it ahead of time / on a side stream
+    (EpipolarTransformer does: ~40 tiny kernels per layer that then hide behind the big ones)."""
+    inner, d_in = w_q.shape
     dh = inner // heads
-    R, d_in = x.shape[0], x.shape[-1]
+    c = w_kv.shape[1]
     d_out = w_out.shape[0]
     P = depth_w.shape[1]
-    # Every linear map on either side of the kernel is folded into ONE weight matrix per side
-    # (tiny [H, c, d] products, differentiable, recomputed each call), so the per-ray work
-    # outside the kernel is a single GEMM in (x -> q~|u|e) and a single GEMM out
-    # (fbar|pbar|abar -> y):  q~_h = (W_k,h^T W_q,h) x,  u_h = W_d^T q~_h,  e_h = E q~_h,
-    # y = sum_h (W_o,h W_v,h)(fbar_h + W_d pbar_h + E^T abar_h + b_d) + b_o.
+    has_e = view_emb is not None
+    wq, wu = heads * c, _pad4(heads * P)
+    we = _pad4(heads * view_emb.shape[0]) if has_e else 0
     w_k = w_kv[:inner].reshape(heads, dh, c)
     w_v = w_kv[inner:].reshape(heads, dh, c)
     m_q = torch.einsum("hkc,hkd->hcd", w_k, w_q.reshape(heads, dh, d_in))       # [H, c, d]
     n_o = torch.einsum("ohk,hkc->ohc", w_out.reshape(d_out, heads, dh), w_v)    # [o, H, c]
-    has_e = view_emb is not None
-    dims = (b, v, h, w, s, c, heads, octaves)
-    wq, wu, we = _FusedEpipolarAttention.widths(dims, has_e)
-
     rows_in = [m_q.reshape(heads * c, d_in),
                torch.einsum("cp,hcd->hpd", depth_w, m_q).reshape(heads * P, d_in)]
     cols_out = [n_o.reshape(d_out, heads * c),
@@ -255,6 +246,32 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     bias = n_o.sum(1) @ depth_b          # softmax weights sum to one
     if b_out is not None:
         bias = bias + b_out
+    return w_in, w_o, bias
+
+
+def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *, w_q: Tensor,
+                          w_kv: Tensor, w_out: Tensor, b_out: Tensor | None, heads: int,
+                          depth_w: Tensor, depth_b: Tensor, octaves: int,
+                          view_emb: Tensor | None = None, return_attn: bool = False,
+                          folded=None):
+    """Attention(x, z=kv) of the reference (attention.py:54-70) for kv = gathered features +
+    Linear(PE(relative disparity)) [+ view embedding], without ever forming kv.
+
+    x [R, 1, d] (already layer-normed), fmap_nhwc [b, v, h, w, c]; w_q [inner, d],
+    w_kv [2*inner, c], w_out [d, inner]; depth_w [c, 2*octaves], depth_b [c];
+    view_emb [v-1, c] (already permuted) or None; `folded` = fold_attention_weights(...) of
+    the same weights when the caller computed it ahead.  Returns [R, 1, d] (and attn [R,H,1,T])."""
+    b, v, h, w, c = fmap_nhwc.shape
+    s = geo.xy_sample.shape[-2]
+    dh = w_q.shape[0] // heads
+    R, d_in = x.shape[0], x.shape[-1]
+    d_out = w_out.shape[0]
+    has_e = view_emb is not None
+    dims = (b, v, h, w, s, c, heads, octaves)
+    if folded is None:
+        folded = fold_attention_weights(w_q=w_q, w_kv=w_kv, w_out=w_out, b_out=b_out, heads=heads,
+                                        depth_w=depth_w, depth_b=depth_b, view_emb=view_emb)
+    w_in, w_o, bias = folded
     qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None)                      # [q~ | u | e]
     fused, attn = _FusedEpipolarAttention.apply(
         dims, float(dh) ** -0.5, has_e, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample,

@@ -227,7 +227,8 @@ def test_epipolar_transformer_module_vs_reference_golden(gpu_device, name, v):
     assert (out.cpu() - g["out"]).abs().max() < 5e-3 * max(scale, 1.0)
     # the hooked (unfused) fallback gives the same result and exposes the attention weights
     seen = []
-    net.transformer.layers[0][0].fn.attend.register_forward_hook(lambda m, i, o: seen.append(o))
+    hook = net.transformer.layers[0][0].fn.attend.register_forward_hook(
+        lambda m, i, o: seen.append(o))
     out2, _ = net(*args, view_shuffle=g["shuffle"].to(dev) if v > 2 else None)
     assert len(seen) == 1 and seen[0].shape[-1] == 4 * (v - 1)
     assert (out2 - out).abs().max() < 1e-4 * max(scale, 1.0)
@@ -235,6 +236,18 @@ def test_epipolar_transformer_module_vs_reference_golden(gpu_device, name, v):
     out.sum().backward()
     missing = [n for n, p in net.named_parameters() if p.grad is None]
     assert missing == []
+    # the side-stream weight folding (forward and, through autograd, backward) gives the same
+    # gradients as folding inline on the main stream
+    hook.remove()
+    g_side = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    net.fold_layers = lambda view_emb=None: [None] * len(net.transformer.layers)
+    out3, _ = net(*args, view_shuffle=g["shuffle"].to(dev) if v > 2 else None)
+    assert torch.equal(out3, out)
+    out3.sum().backward()
+    for n, p in net.named_parameters():
+        ref = p.grad
+        assert (g_side[n] - ref).abs().max() <= 1e-5 * max(ref.abs().max().item(), 1e-6), n
 
 
 @pytest.mark.parametrize("m,n,k", [(512, 128, 4096), (128, 512, 1000), (80, 128, 777), (128, 80, 258),
