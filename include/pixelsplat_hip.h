@@ -256,7 +256,7 @@ int ps_invert_cameras(int32_t n, const float* c2w, const float* k, float* w2c, f
  * fixed-order reduction: the weight gradients of the folded attention matrices
  * (dW = dY^T X over all rays; autograd of the Linear layers at attention.py:36-45,
  * epipolar_transformer.py:61-66).  A, B row-major with leading dimensions lda >= m,
- * ldb >= n (multiples of 4, 16-byte aligned), n % 4 == 0.  workspace: ps_gemm_tn_workspace_bytes. */
+ * ldb >= n (multiples of 4, 16-byte aligned), m % 4 == 0, n % 4 == 0.  workspace: ps_gemm_tn_workspace_bytes. */
 size_t ps_gemm_tn_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int ps_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda, const float* b,
                    int32_t ldb, float* c, void* workspace, size_t workspace_bytes, void* stream);

@@ -11,8 +11,8 @@
 // different m (or n) for the same k; MFMA (ja, jb) takes component ja of the A vector and jb
 // of the B vector, i.e. it computes the rows {4 i + ja} x columns {4 i' + jb} of the tile --
 // an interleaved sub-tile, undone when the partial tile is stored.  Two 16-byte loads feed
-// 16 MFMAs (1024 MFMA cycles), so a single wave per SIMD with a two-step register prefetch
-// is enough.  Partials are summed in a fixed order by a second kernel: deterministic.
+// 16 MFMAs (1024 MFMA cycles); a single wave per SIMD keeps six k-steps of operands in
+// flight in registers.  Partials are summed in a fixed order by a second kernel: deterministic.
 #include "raster_common.h"
 
 namespace ps {
@@ -21,6 +21,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kGemmTile = 128;
 constexpr int kGemmWaves = 1024;     // one 512-register wave per SIMD: 256 CUs x 4
+constexpr int kGemmPrefetch = 6;     // k-steps of operands in flight per wave
 
 struct GemmPlan { int tiles_m, tiles_n, chunks, rows; };
 // k is cut so that tiles x chunks fills the machine once
@@ -49,16 +50,16 @@ gemm_tn_partial_kernel(int M, int N, int K, int rows, const float* __restrict__ 
   const int k_begin = chunk * rows, k_end = min(k_begin + rows, K);
   // this lane's 4 consecutive m (n): m0 + 4 q + j
   const int ma = m0 + 4 * q, nb = n0 + 4 * q;
-  const bool a_full = ma + 3 < M, b_full = nb + 3 < N;
-
-  auto load4 = [](const float* __restrict__ row, int c, int lim, bool full, bool row_ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!row_ok) return v;
-    if (full) return *reinterpret_cast<const float4*>(row + c);
-    if (c < lim) v.x = row[c];
-    if (c + 1 < lim) v.y = row[c + 1];
-    if (c + 2 < lim) v.z = row[c + 2];
-    return v;       // c + 3 >= lim here
+  // M and N are multiples of 4, so a lane's four columns are all inside or all outside.
+  // Loads are branch-free (clamped address + select): with loads inside divergent branches the
+  // compiler waits for vmcnt(0) before every MFMA group and the prefetch ring is useless.
+  const bool a_in = ma < M, b_in = nb < N;
+  const int mac = a_in ? ma : 0, nbc = b_in ? nb : 0;
+  auto load4 = [k_end](const float* __restrict__ base, int ld, int k, int col, bool in) {
+    const int kc = k < k_end ? k : k_end - 1;
+    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)kc * ld + col);
+    const bool ok = in && k < k_end;
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   };
 
   floatx16 acc[4][4];
@@ -69,28 +70,30 @@ gemm_tn_partial_kernel(int M, int N, int K, int rows, const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // two-step prefetch ring
-  float4 a0, b0, a1, b1;
-  {
-    const int k = k_begin + kk;
-    a0 = load4(A + (size_t)k * lda, ma, M, a_full, k < k_end);
-    b0 = load4(B + (size_t)k * ldb, nb, N, b_full, k < k_end);
-    const int k2 = k + 2;
-    a1 = load4(A + (size_t)k2 * lda, ma, M, a_full, k2 < k_end);
-    b1 = load4(B + (size_t)k2 * ldb, nb, N, b_full, k2 < k_end);
+  // register prefetch ring, kGemmPrefetch k-steps (of 2 rows) deep: one wave per SIMD has
+  // nobody to hide an HBM miss behind, the loads must be ~2 us ahead of their MFMAs
+  float4 ra[kGemmPrefetch], rb[kGemmPrefetch];
+#pragma unroll
+  for (int u = 0; u < kGemmPrefetch; ++u) {
+    const int k = k_begin + 2 * u + kk;
+    ra[u] = load4(A, lda, k, mac, a_in);
+    rb[u] = load4(B, ldb, k, nbc, b_in);
   }
-  for (int ks = k_begin; ks < k_end; ks += 2) {
-    const float4 a = a0, b = b0;
-    a0 = a1; b0 = b1;
-    const int k2 = ks + 4 + kk;
-    a1 = load4(A + (size_t)k2 * lda, ma, M, a_full, k2 < k_end);
-    b1 = load4(B + (size_t)k2 * ldb, nb, N, b_full, k2 < k_end);
-    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  for (int ks = k_begin; ks < k_end; ks += 2 * kGemmPrefetch) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < kGemmPrefetch; ++u) {
+      const float4 a = ra[u], b = rb[u];
+      const int k2 = ks + 2 * (u + kGemmPrefetch) + kk;
+      ra[u] = load4(A, lda, k2, mac, a_in);
+      rb[u] = load4(B, ldb, k2, nbc, b_in);
+      // rows past k_end were loaded as zeros: the extra MFMAs of the last group add nothing
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
   }
   // store: MFMA (i, j), register e of lane l is row 8 (e / 4) + 4 (l / 32) + e % 4, column
   // l % 32 of the 32x32 block, i.e. tile row 4 * row + i, tile column 4 * col + j
@@ -146,7 +149,7 @@ size_t gemm_tn_workspace_bytes(int M, int N, int K) {
 int launch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                    float* C, float* workspace, hipStream_t st) {
   // float4 loads/stores need 16-byte aligned rows
-  if ((lda & 3) || (ldb & 3) || (N & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+  if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
       ((uintptr_t)workspace & 15))
     return PS_ERR_UNSUPPORTED;
   const GemmPlan p = gemm_tn_plan(M, N, K);

@@ -98,10 +98,12 @@ def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
     lib = _lib.load()
     k, m = a.shape
     n = b.shape[1]
-    if n % 4:                      # the kernel stores rows of C as float4
+    if n % 4:                      # the kernel works on groups of 4 columns
         return gemm_tn(a, torch.nn.functional.pad(b, (0, -n % 4)))[:, :n]
+    if m % 4:
+        return gemm_tn(torch.nn.functional.pad(a, (0, -m % 4)), b)[:m]
     if a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
-        a = torch.nn.functional.pad(a, (0, -m % 4))[:, :m] if m % 4 else a.contiguous()
+        a = a.contiguous()
     if b.stride(1) != 1 or b.stride(0) % 4 or b.data_ptr() % 16:
         b = b.contiguous()
     c = torch.empty((m, n), dtype=torch.float32, device=a.device)
