@@ -67,6 +67,25 @@ def pmc_traffic(group):
     return None, None
 
 
+def pmc_valu_busy_ms(group):
+    """VALU-issue time per launch (SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs at 2.4 GHz) of
+    the kernel behind a profile group, from the committed PMC summary (tools/pmc_sq_summary.py)."""
+    import glob
+    key = {"tiles_backward": "tiles_backward_kernel", "tiles_forward": "tiles_forward_kernel",
+           "epipolar_attention_forward": "epipolar_attn_forward_kernel",
+           "epipolar_attention_backward": "epipolar_attn_backward_kernel",
+           "epipolar_feature_grad": "epipolar_dfmap_kernel"}.get(group)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq.json")))
+    if key is None or not files:
+        return None
+    with open(files[-1]) as f:
+        kernels = json.load(f)["kernels"]
+    for name, v in kernels.items():
+        if key in name:
+            return v.get("valu_busy_ms_at_2.4GHz")
+    return None
+
+
 def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     """The oracle (CPU port of the same algorithm) timed on the host cores over a bounded
     sample of the same workload: the first `n_views` views of the batch (scene-major),
@@ -276,6 +295,7 @@ def main():
         dom_ms = groups[dom][0]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dom)
+        valu_ms = pmc_valu_busy_ms(dom)
         out = {
             "metric": "rendered views/sec (fwd+bwd)", "value": round(value, 2), "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -296,6 +316,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "avg_kernel_ms": round(dom_ms, 4),
+                # the dominant kernel is VALU-issue bound, not HBM bound: share of
+                # its time the SIMDs spend issuing VALU instructions, from the committed PMC run
+                "valu_issue_frac": (round(valu_ms / dom_ms, 3) if valu_ms else None),
                 "algorithmic_bytes_per_launch": alg[dom],
             },
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},
