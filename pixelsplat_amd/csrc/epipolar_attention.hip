@@ -308,10 +308,14 @@ __device__ __forceinline__ void stage_chunk(const AttnDims& dm, const RayCtx& k,
     if (tl < kChunk && t < k.T && ch < dm.c) {
       const int4 off = *reinterpret_cast<const int4*>(k.tokS + t * 8);
       const float4 wt = *reinterpret_cast<const float4*>(k.tokS + t * 8 + 4);
-      const float4 p0 = *reinterpret_cast<const float4*>(fmap + (size_t)off.x * dm.c + ch);
-      const float4 p1 = *reinterpret_cast<const float4*>(fmap + (size_t)off.y * dm.c + ch);
-      const float4 p2 = *reinterpret_cast<const float4*>(fmap + (size_t)off.z * dm.c + ch);
-      const float4 p3 = *reinterpret_cast<const float4*>(fmap + (size_t)off.w * dm.c + ch);
+      // 32-bit byte offsets from the (wave-uniform) map pointer: scalar base + vector offset
+      // addressing instead of a 64-bit multiply-add per corner (the maps are < 4 GB, checked)
+      const char* fm = reinterpret_cast<const char*>(fmap);
+      const uint32_t cb = 4u * (uint32_t)dm.c, chb = 4u * (uint32_t)ch;
+      const float4 p0 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.x * cb + chb));
+      const float4 p1 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.y * cb + chb));
+      const float4 p2 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.z * cb + chb));
+      const float4 p3 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.w * cb + chb));
       float4 f;
       f.x = fmaf(p3.x, wt.w, fmaf(p2.x, wt.z, fmaf(p1.x, wt.y, p0.x * wt.x)));
       f.y = fmaf(p3.y, wt.w, fmaf(p2.y, wt.z, fmaf(p1.y, wt.y, p0.y * wt.x)));
@@ -847,7 +851,8 @@ static bool attn_dims_ok(const AttnDims& dm) {
          dm.s * (dm.v - 1) <= 128 && dm.s * (dm.v - 1) >= 1 && 2 * dm.octaves <= 8 * kUPL &&
          dm.octaves >= 1 && dm.c % 4 == 0 && dm.c >= 4 && dm.c <= 256 && dm.ld_q % 4 == 0 &&
          dm.ld_f % 4 == 0 &&
-         (size_t)dm.b * dm.v * dm.h * dm.w < (size_t)1 << 30;
+         (size_t)dm.b * dm.v * dm.h * dm.w < (size_t)1 << 30 &&
+         (size_t)dm.b * dm.v * dm.h * dm.w * dm.c * 4 < ((size_t)1 << 32);
 }
 
 int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* xy,
