@@ -63,15 +63,26 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
       const uint2 r = rects[vg];
       const uint32_t area = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
       if (area <= (uint32_t)kInvSlots) {
-        for (uint32_t k = 0; k < area; ++k) {
-          const uint32_t pos = inv_slots[vg * kInvSlots + k];
-          if (pos < capacity) {
-            const float4* tg = reinterpret_cast<const float4*>(tile_grads + (size_t)pos * kSlotFloats);
-            const float4 t0 = tg[0], t1 = tg[1];
-            const float t2 = tile_grads[(size_t)pos * kSlotFloats + 8];
-            gr[0] += t0.x; gr[1] += t0.y; gr[2] += t0.z; gr[3] += t0.w;
-            gr[4] += t1.x; gr[5] += t1.y; gr[6] += t1.z; gr[7] += t1.w; gr[8] += t2;
-          }
+        // all slot loads are issued before the first add (one index load + up to 4 slots in
+        // flight instead of a chain of 8 dependent latencies); the sum keeps the tile order
+        const uint4 iv = *reinterpret_cast<const uint4*>(inv_slots + vg * kInvSlots);
+        const uint32_t posk[kInvSlots] = {iv.x, iv.y, iv.z, iv.w};
+        float4 a0[kInvSlots], a1[kInvSlots];
+        float a2[kInvSlots];
+#pragma unroll
+        for (int k = 0; k < kInvSlots; ++k) {
+          const bool on = (uint32_t)k < area && posk[k] < capacity;
+          const float* sp = tile_grads + (size_t)(on ? posk[k] : 0u) * kSlotFloats;
+          const float4* tg = reinterpret_cast<const float4*>(sp);
+          a0[k] = on ? tg[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+          a1[k] = on ? tg[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+          a2[k] = on ? sp[8] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kInvSlots; ++k) {
+          gr[0] += a0[k].x; gr[1] += a0[k].y; gr[2] += a0[k].z; gr[3] += a0[k].w;
+          gr[4] += a1[k].x; gr[5] += a1[k].y; gr[6] += a1[k].z; gr[7] += a1[k].w;
+          gr[8] += a2[k];
         }
         // the SH backward kernel reads the colour gradient from grad2d
         float* go = grad2d + vg * kGradFloats;
