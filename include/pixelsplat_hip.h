@@ -227,6 +227,11 @@ typedef struct PsEpipolarDesc {
    * (one GEMM produces them), likewise the outputs.  ld_q and ld_f must be multiples of 4
    * and the qt / fbar / dfbar pointers 16-byte aligned. */
   int32_t ld_q, ld_u, ld_e, ld_f, ld_p, ld_a;
+  /* head strides in floats inside a row (0 = each array keeps its heads contiguous: c, P,
+   * v-1).  With hs_in = c + P + (v-1) (padded to a multiple of 4) and qt, u, e pointing at
+   * columns 0, c, c + P, a row is [q~_0 u_0 e_0 | q~_1 u_1 e_1 | ...]: the layout a batched
+   * per-head GEMM produces without any permutation; hs_out likewise for fbar / pbar / abar. */
+  int32_t hs_in, hs_out;
 } PsEpipolarDesc;
 int ps_epipolar_gather(const PsEpipolarDesc* desc, const float* fmap, const float* xy_sample,
                        const uint8_t* flags, float* features /*[b][v][v-1][h*w][s][c]*/,
@@ -243,7 +248,8 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap
                                    const float* abar /* NULL when e was NULL */,
                                    const float* dfbar, const float* dpbar,
                                    const float* dabar /* may be NULL */, float scale,
-                                   float* dqt, float* du, float* de, float* ds, float* dfmap,
+                                   float* dqt, float* du, float* de /* may be NULL */, float* ds,
+                                   float* dfmap,
                                    uint32_t* ray_boxes, void* stream);
 
 /* w2c[i] = c2w[i]^-1 (4x4) and k_inv[i] = k[i]^-1 (3x3) for n cameras, one launch, no host

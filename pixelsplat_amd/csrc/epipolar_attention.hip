@@ -335,10 +335,13 @@ struct QueryRegs {
 };
 
 __device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, int lane,
-                                           const float* __restrict__ qrow,
-                                           const float* __restrict__ urow, QueryRegs& Q) {
-  for (int i = lane * 4; i < k.H * dm.c; i += kWave * 4)
-    *reinterpret_cast<float4*>(k.qS + i) = *reinterpret_cast<const float4*>(qrow + i);
+                                           const float* __restrict__ qrow, int hs_q,
+                                           const float* __restrict__ urow, int hs_u,
+                                           QueryRegs& Q) {
+  for (int hh = 0; hh < k.H; ++hh)
+    for (int i = lane * 4; i < dm.c; i += kWave * 4)
+      *reinterpret_cast<float4*>(k.qS + hh * dm.c + i) =
+          *reinterpret_cast<const float4*>(qrow + hh * hs_q + i);
   const int j = lane & 7;
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
@@ -346,7 +349,7 @@ __device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, 
 #pragma unroll
     for (int i = 0; i < kUPL; ++i) {
       const int p = j + 8 * i;
-      Q.u[hh][i] = (p < k.P && hh < k.H) ? urow[hs * k.P + p] : 0.f;
+      Q.u[hh][i] = (p < k.P && hh < k.H) ? urow[hs * hs_u + p] : 0.f;
     }
   }
   wave_lds_sync();
@@ -357,7 +360,7 @@ __device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, 
 template <int CK>
 __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k, int lane, int t0,
                                              const QueryRegs& Q, const float* __restrict__ erow,
-                                             float (&out)[kMaxHeads]) {
+                                             int hs_e, float (&out)[kMaxHeads]) {
   const int tl = lane >> 3, j = lane & 7;
   const float* frow = k.featS + tl * k.fs;
   float acc[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
@@ -387,7 +390,7 @@ __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k
     const int ov = min(t0 + tl, k.T - 1) % k.ovn;
 #pragma unroll
     for (int hh = 0; hh < kMaxHeads; ++hh)
-      if (hh < k.H) acc[hh] += erow[hh * k.ovn + ov];
+      if (hh < k.H) acc[hh] += erow[hh * hs_e + ov];
   }
   group8_sum4(acc[0], acc[1], acc[2], acc[3]);
 #pragma unroll
@@ -463,7 +466,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   stage_records(dm, k, lane, xy, flags, rd);
   QueryRegs Q;
   const size_t ray = (size_t)k.ray;
-  load_query(dm, k, lane, qt + ray * dm.ld_q, u + ray * dm.ld_u, Q);
+  load_query(dm, k, lane, qt + ray * dm.ld_q, dm.hs_q, u + ray * dm.ld_u, dm.hs_u, Q);
   const float* erow = e ? e + ray * dm.ld_e : nullptr;
 
   ContextRegs<CK> A;
@@ -476,7 +479,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float sc[kMaxHeads];
-    chunk_scores<CK>(dm, k, lane, t0, Q, erow, sc);
+    chunk_scores<CK>(dm, k, lane, t0, Q, erow, dm.hs_e, sc);
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
     float mx[kMaxHeads];
@@ -512,10 +515,10 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     const float inv = 1.0f / l_run[hh];
     if (c0 < dm.c) {
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) fbar[ray * dm.ld_f + hh * dm.c + c0 + i] = A.f[hh][i] * inv;
+      for (int i = 0; i < CPL; ++i) fbar[ray * dm.ld_f + hh * dm.hs_f + c0 + i] = A.f[hh][i] * inv;
     }
-    if (lane < k.P) pbar[ray * dm.ld_p + hh * k.P + lane] = A.p[hh] * inv;
-    if (e != nullptr && lane < k.ovn) abar[ray * dm.ld_a + hh * k.ovn + lane] = A.o[hh] * inv;
+    if (lane < k.P) pbar[ray * dm.ld_p + hh * dm.hs_p + lane] = A.p[hh] * inv;
+    if (e != nullptr && lane < k.ovn) abar[ray * dm.ld_a + hh * dm.hs_a + lane] = A.o[hh] * inv;
     for (int t = lane; t < k.T; t += kWave)
       attn[(rh + hh) * k.T + t] = __expf(k.scS[hh * k.T + t] - m_run[hh]) * inv;
   }
@@ -548,7 +551,7 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   stage_records(dm, k, lane, xy, flags, rd);
   QueryRegs Q;
   const size_t ray = (size_t)k.ray;
-  load_query(dm, k, lane, dfbar + ray * dm.ld_f, dpbar + ray * dm.ld_p, Q);
+  load_query(dm, k, lane, dfbar + ray * dm.ld_f, dm.hs_f, dpbar + ray * dm.ld_p, dm.hs_p, Q);
   const float* erow = dabar ? dabar + ray * dm.ld_a : nullptr;
 
   ContextRegs<CK> A;
@@ -558,7 +561,7 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float da[kMaxHeads];
-    chunk_scores<CK>(dm, k, lane, t0, Q, erow, da);
+    chunk_scores<CK>(dm, k, lane, t0, Q, erow, dm.hs_a, da);
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
 #pragma unroll
@@ -582,17 +585,17 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
     if (c0 < dm.c) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i)
-        dqt[ray * dm.ld_q + hh * dm.c + c0 + i] =
-            scale * (A.f[hh][i] - d * fbar[ray * dm.ld_f + hh * dm.c + c0 + i]);
+        dqt[ray * dm.ld_q + hh * dm.hs_q + c0 + i] =
+            scale * (A.f[hh][i] - d * fbar[ray * dm.ld_f + hh * dm.hs_f + c0 + i]);
     }
     if (lane < k.P)
-      du[ray * dm.ld_u + hh * k.P + lane] =
-          scale * (A.p[hh] - d * pbar[ray * dm.ld_p + hh * k.P + lane]);
-    if (lane < k.ovn) {
+      du[ray * dm.ld_u + hh * dm.hs_u + lane] =
+          scale * (A.p[hh] - d * pbar[ray * dm.ld_p + hh * dm.hs_p + lane]);
+    if (de != nullptr && lane < k.ovn) {
       // abar is only produced when the view embedding exists; otherwise it is the softmax mass
       // of the single other view, i.e. one
-      const float ab = abar ? abar[ray * dm.ld_a + hh * k.ovn + lane] : 1.0f;
-      de[ray * dm.ld_e + hh * k.ovn + lane] = scale * (A.o[hh] - d * ab);
+      const float ab = abar ? abar[ray * dm.ld_a + hh * dm.hs_a + lane] : 1.0f;
+      de[ray * dm.ld_e + hh * dm.hs_e + lane] = scale * (A.o[hh] - d * ab);
     }
     for (int t = lane; t < k.T; t += kWave)
       ds_out[(rh + hh) * k.T + t] =
@@ -759,8 +762,8 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
           x.av[hh] = attn[rowh * T + si * ovn + ov];
           x.dv[hh] = ds[rowh * T + si * ovn + ov];
           const int hs = hh < H ? hh : 0;
-          load_cpl<CPL>(dfbar + ray * dm.ld_f + hs * dm.c + cl, x.gq[hh]);
-          load_cpl<CPL>(qt + ray * dm.ld_q + hs * dm.c + cl, x.qq[hh]);
+          load_cpl<CPL>(dfbar + ray * dm.ld_f + hs * dm.hs_f + cl, x.gq[hh]);
+          load_cpl<CPL>(qt + ray * dm.ld_q + hs * dm.hs_q + cl, x.qq[hh]);
         }
       };
       const int n_items = count * ngroups;
@@ -850,7 +853,7 @@ static bool attn_dims_ok(const AttnDims& dm) {
   return attn_smem(dm) <= 160 * 1024 && dm.heads >= 1 && dm.heads <= kMaxHeads &&
          dm.s * (dm.v - 1) <= 128 && dm.s * (dm.v - 1) >= 1 && 2 * dm.octaves <= 8 * kUPL &&
          dm.octaves >= 1 && dm.c % 4 == 0 && dm.c >= 4 && dm.c <= 256 && dm.ld_q % 4 == 0 &&
-         dm.ld_f % 4 == 0 &&
+         dm.ld_f % 4 == 0 && dm.hs_q % 4 == 0 && dm.hs_f % 4 == 0 &&
          (size_t)dm.b * dm.v * dm.h * dm.w < (size_t)1 << 30 &&
          (size_t)dm.b * dm.v * dm.h * dm.w * dm.c * 4 < ((size_t)1 << 32);
 }

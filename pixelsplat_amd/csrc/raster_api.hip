@@ -266,7 +266,9 @@ AttnDims to_dims(const PsEpipolarDesc* d) {
   auto ld = [](int given, int dflt) { return given > 0 ? given : dflt; };
   return AttnDims{d->b, d->v, d->h, d->w, d->s, d->c, d->heads, d->octaves,
                   ld(d->ld_q, H * d->c), ld(d->ld_u, H * P), ld(d->ld_e, H * ov),
-                  ld(d->ld_f, H * d->c), ld(d->ld_p, H * P), ld(d->ld_a, H * ov)};
+                  ld(d->ld_f, H * d->c), ld(d->ld_p, H * P), ld(d->ld_a, H * ov),
+                  ld(d->hs_in, d->c), ld(d->hs_in, P), ld(d->hs_in, ov),
+                  ld(d->hs_out, d->c), ld(d->hs_out, P), ld(d->hs_out, ov)};
 }
 }  // namespace
 
@@ -304,7 +306,7 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
                                    float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
                                    void* stream) {
   if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !fbar ||
-      !pbar || !dfbar || !dpbar || !dqt || !du || !de || !ds || (dfmap && !ray_boxes))
+      !pbar || !dfbar || !dpbar || !dqt || !du || !ds || (dfmap && !ray_boxes))
     return PS_ERR_BAD_ARG;
   {
     Scope sc(G_EPI_BWD, (hipStream_t)stream);

@@ -146,7 +146,10 @@ void launch_epipolar_geometry(int b, int v, int h, int w, int s, const float* c2
 // ld_*: row strides (floats) of the per-ray arrays qt / u / e (and dqt / du / de) and
 // fbar / pbar / abar (and their gradients), so that they may be column blocks of one matrix;
 // inside a row heads are contiguous ([h][c], [h][P], [h][v-1]).
-struct AttnDims { int b, v, h, w, s, c, heads, octaves, ld_q, ld_u, ld_e, ld_f, ld_p, ld_a; };
+struct AttnDims {
+  int b, v, h, w, s, c, heads, octaves, ld_q, ld_u, ld_e, ld_f, ld_p, ld_a;
+  int hs_q, hs_u, hs_e, hs_f, hs_p, hs_a;   // head strides inside a row (default c, P, v-1)
+};
 int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* xy,
                            const uint8_t* flags, float* out, hipStream_t st);
 int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const float* xy,

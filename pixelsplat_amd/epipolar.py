@@ -142,37 +142,43 @@ def _pad4(n: int) -> int:
 
 
 class _FusedEpipolarAttention(torch.autograd.Function):
-    """(fmap, [q~ | u | e]) -> ([fbar | pbar | abar], attn); see csrc/epipolar_attention.hip.
+    """(fmap, qin) -> (out, attn); see csrc/epipolar_attention.hip.
 
-    Inputs and outputs of the kernel are column blocks of ONE row-major matrix each (block
-    widths padded to multiples of 4 floats), so one GEMM feeds the kernel and one consumes it.
-    """
+    qin and out are ONE row-major matrix each, a row being the heads' blocks
+    [q~_h (c) | u_h (P) | e_h (v-1) | pad] resp. [fbar_h | pbar_h | abar_h | pad] of width
+    Lh = head_width(...): exactly what a batched per-head GEMM produces / consumes, so one GEMM
+    feeds the kernel and one consumes it, with no permutation or concatenation in between."""
 
     @staticmethod
-    def widths(dims, has_e):
+    def head_width(c, octaves, ov, has_e):
+        return _pad4(c + 2 * octaves + (ov if has_e else 0))
+
+    @staticmethod
+    def _desc(dims, has_e):
         b, v, h, w, s, c, heads, octaves = dims
-        return heads * c, _pad4(heads * 2 * octaves), (_pad4(heads * (v - 1)) if has_e else 0)
+        lh = _FusedEpipolarAttention.head_width(c, octaves, v - 1, has_e)
+        d = _desc(*dims)
+        d.ld_q = d.ld_u = d.ld_e = d.ld_f = d.ld_p = d.ld_a = heads * lh
+        d.hs_in = d.hs_out = lh
+        return d, lh
 
     @staticmethod
     def forward(ctx, dims, scale, has_e, fmap, xy, flags, rd, qin):
         lib = _lib.load()
         b, v, h, w, s, c, heads, octaves = dims
-        R, T = b * v * h * w, s * (v - 1)
-        wq, wu, we = _FusedEpipolarAttention.widths(dims, has_e)
-        ld = wq + wu + we
+        R, T, P = b * v * h * w, s * (v - 1), 2 * octaves
+        d, lh = _FusedEpipolarAttention._desc(dims, has_e)
         fmap, qin = fmap.contiguous(), qin.contiguous()
-        assert qin.shape == (R, ld)
-        d = _desc(*dims)
-        d.ld_q = d.ld_u = d.ld_e = d.ld_f = d.ld_p = d.ld_a = ld
-        padded = wu != heads * 2 * octaves or (has_e and we != heads * (v - 1))
-        out = (torch.zeros if padded else torch.empty)((R, ld), dtype=torch.float32,
+        assert qin.shape == (R, heads * lh)
+        padded = lh != c + P + ((v - 1) if has_e else 0)
+        out = (torch.zeros if padded else torch.empty)((R, heads * lh), dtype=torch.float32,
                                                        device=fmap.device)
         attn = torch.empty((R, heads, T), dtype=torch.float32, device=fmap.device)
         col = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
         _lib.check(lib.ps_epipolar_attention_forward(
-            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), col(qin, 0), col(qin, wq),
-            col(qin, wq + wu) if has_e else None, C.c_float(scale), col(out, 0), col(out, wq),
-            col(out, wq + wu), _p(attn), _stream()), "ps_epipolar_attention_forward")
+            C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), col(qin, 0), col(qin, c),
+            col(qin, c + P) if has_e else None, C.c_float(scale), col(out, 0), col(out, c),
+            col(out, c + P), _p(attn), _stream()), "ps_epipolar_attention_forward")
         ctx.dims, ctx.scale, ctx.has_e, ctx.padded = dims, scale, has_e, padded
         ctx.save_for_backward(fmap, xy, flags, rd, qin, attn, out)
         ctx.mark_non_differentiable(attn)
@@ -183,29 +189,23 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         lib = _lib.load()
         fmap, xy, flags, rd, qin, attn, out = ctx.saved_tensors
         b, v, h, w, s, c, heads, octaves = ctx.dims
-        R, T, ov = b * v * h * w, s * (v - 1), v - 1
-        wq, wu, we = _FusedEpipolarAttention.widths(ctx.dims, ctx.has_e)
-        ld = wq + wu + we
-        d = _desc(*ctx.dims)
-        d.ld_q = d.ld_u = d.ld_e = d.ld_f = d.ld_p = d.ld_a = ld
+        R, T, P, ov = b * v * h * w, s * (v - 1), 2 * octaves, v - 1
+        d, lh = _FusedEpipolarAttention._desc(ctx.dims, ctx.has_e)
         dout = dout.contiguous()
         f32 = dict(dtype=torch.float32, device=fmap.device)
-        dqin = (torch.zeros if ctx.padded else torch.empty)((R, ld), **f32)
-        de_scratch = None if ctx.has_e else torch.empty((R, heads * ov), **f32)
+        dqin = (torch.zeros if ctx.padded else torch.empty)((R, heads * lh), **f32)
         ds = torch.empty((R, heads, T), **f32)
         dfmap = boxes = None
         if ctx.needs_input_grad[3]:
             dfmap = torch.empty_like(fmap)
             boxes = torch.empty((R * ov,), dtype=torch.int32, device=fmap.device)
         col = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
-        if not ctx.has_e:           # de is still written (unused): give it its own buffer
-            d.ld_e = heads * ov
+        de = col(dqin, c + P) if ctx.has_e else None
         _lib.check(lib.ps_epipolar_attention_backward(
             C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), col(qin, 0), _p(attn), col(out, 0),
-            col(out, wq), col(out, wq + wu) if ctx.has_e else None,
-            col(dout, 0), col(dout, wq), col(dout, wq + wu) if ctx.has_e else None,
-            C.c_float(ctx.scale), col(dqin, 0), col(dqin, wq),
-            col(dqin, wq + wu) if ctx.has_e else _p(de_scratch), _p(ds), _p(dfmap), _p(boxes),
+            col(out, c), col(out, c + P) if ctx.has_e else None,
+            col(dout, 0), col(dout, c), col(dout, c + P) if ctx.has_e else None,
+            C.c_float(ctx.scale), col(dqin, 0), col(dqin, c), de, _p(ds), _p(dfmap), _p(boxes),
             _stream()), "ps_epipolar_attention_backward")
         return (None, None, None, dfmap, None, None, None, dqin)
 
@@ -213,42 +213,37 @@ class _FusedEpipolarAttention(torch.autograd.Function):
 def fold_attention_weights(*, w_q: Tensor, w_kv: Tensor, w_out: Tensor, b_out: Tensor | None,
                            heads: int, depth_w: Tensor, depth_b: Tensor,
                            view_emb: Tensor | None = None):
-    """Every linear map on either side of the kernel folded into ONE weight matrix per side
-    (tiny [H, c, d] products, differentiable, recomputed each call):
-        q~_h = (W_k,h^T W_q,h) x,  u_h = W_d^T q~_h,  e_h = E q~_h          -> W_in  [ld, d]
-        y = sum_h (W_o,h W_v,h)(fbar_h + W_d pbar_h + E^T abar_h + b_d) + b_o -> W_o [d_out, ld], bias
-    Depends on the weights only, so a caller may run it ahead of time / on a side stream
-    (EpipolarTransformer does: ~40 tiny kernels per layer that then hide behind the big ones)."""
+    """Every linear map on either side of the kernel folded into ONE weight matrix per side.
+    With A = [I_c; W_d^T; E] (rows: identity, depth-encoding weights, view embeddings):
+        [q~_h; u_h; e_h] = (A W_k,h^T) W_q,h x                       -> w_in   [H*Lh, d]
+        y = sum_h W_o,h (W_v,h A^T) [fbar_h; pbar_h; abar_h] + bias   -> w_o_t  [H*Lh, d_out]
+        bias = b_o + sum_h W_o,h W_v,h b_d                            (softmax weights sum to 1)
+    Seven small launches (two matmuls per side + bias), differentiable through autograd,
+    recomputed every call; rows are laid out per head, which is the kernel's layout."""
     inner, d_in = w_q.shape
     dh = inner // heads
     c = w_kv.shape[1]
     d_out = w_out.shape[0]
     P = depth_w.shape[1]
     has_e = view_emb is not None
-    wq, wu = heads * c, _pad4(heads * P)
-    we = _pad4(heads * view_emb.shape[0]) if has_e else 0
+    lh = _pad4(c + P + (view_emb.shape[0] if has_e else 0))
+    rows = [torch.eye(c, device=w_q.device, dtype=w_q.dtype), depth_w.T]
+    if has_e:
+        rows.append(view_emb)
+    n_rows = c + P + (view_emb.shape[0] if has_e else 0)
+    if lh != n_rows:
+        rows.append(torch.zeros((lh - n_rows, c), device=w_q.device, dtype=w_q.dtype))
+    a_full = torch.cat(rows, 0)                                        # [Lh, c]
     w_k = w_kv[:inner].reshape(heads, dh, c)
     w_v = w_kv[inner:].reshape(heads, dh, c)
-    m_q = torch.einsum("hkc,hkd->hcd", w_k, w_q.reshape(heads, dh, d_in))       # [H, c, d]
-    n_o = torch.einsum("ohk,hkc->ohc", w_out.reshape(d_out, heads, dh), w_v)    # [o, H, c]
-    rows_in = [m_q.reshape(heads * c, d_in),
-               torch.einsum("cp,hcd->hpd", depth_w, m_q).reshape(heads * P, d_in)]
-    cols_out = [n_o.reshape(d_out, heads * c),
-                torch.einsum("ohc,cp->ohp", n_o, depth_w).reshape(d_out, heads * P)]
-    widths = [wq, wu]
-    if has_e:
-        ovn = view_emb.shape[0]
-        rows_in.append(torch.einsum("oc,hcd->hod", view_emb, m_q).reshape(heads * ovn, d_in))
-        cols_out.append(torch.einsum("ohc,vc->ohv", n_o, view_emb).reshape(d_out, heads * ovn))
-        widths.append(we)
-    pad_r = lambda m, wd: m if m.shape[0] == wd else torch.nn.functional.pad(m, (0, 0, 0, wd - m.shape[0]))
-    pad_c = lambda m, wd: m if m.shape[1] == wd else torch.nn.functional.pad(m, (0, wd - m.shape[1]))
-    w_in = torch.cat([pad_r(m, wd) for m, wd in zip(rows_in, widths)], 0)       # [ld, d]
-    w_o = torch.cat([pad_c(m, wd) for m, wd in zip(cols_out, widths)], 1)       # [d_out, ld]
-    bias = n_o.sum(1) @ depth_b          # softmax weights sum to one
-    if b_out is not None:
-        bias = bias + b_out
-    return w_in, w_o, bias
+    k_t = torch.matmul(a_full, w_k.transpose(1, 2))                    # [H, Lh, dh] = A W_k^T
+    w_in = torch.bmm(k_t, w_q.reshape(heads, dh, d_in)).reshape(heads * lh, d_in)
+    v_t = torch.matmul(a_full, w_v.transpose(1, 2))                    # [H, Lh, dh] = A W_v^T
+    w_o_h = w_out.reshape(d_out, heads, dh).permute(1, 2, 0)           # [H, dh, d_out] (view)
+    w_o_t = torch.bmm(v_t, w_o_h).reshape(heads * lh, d_out)
+    vb = torch.matmul(w_v, depth_b).reshape(inner)                     # W_v,h b_d
+    bias = torch.mv(w_out, vb) if b_out is None else torch.addmv(b_out, w_out, vb)
+    return w_in, w_o_t, bias
 
 
 def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *, w_q: Tensor,
@@ -273,12 +268,12 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     if folded is None:
         folded = fold_attention_weights(w_q=w_q, w_kv=w_kv, w_out=w_out, b_out=b_out, heads=heads,
                                         depth_w=depth_w, depth_b=depth_b, view_emb=view_emb)
-    w_in, w_o, bias = folded
-    qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None)                      # [q~ | u | e]
+    w_in, w_o_t, bias = folded
+    qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None)              # heads x [q~ | u | e]
     fused, attn = _FusedEpipolarAttention.apply(
         dims, float(dh) ** -0.5, has_e, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample,
         geo.flags, geo.rel_disparity, qin)
-    out = _RayLinear.apply(fused, w_o, bias).reshape(R, 1, d_out)
+    out = _RayLinear.apply(fused, w_o_t.T, bias).reshape(R, 1, d_out)
     if return_attn:
         return out, attn.reshape(R, heads, 1, -1)
     return out
