@@ -63,3 +63,43 @@ def test_parameter_names_match_live_reference_at_paper_config():
     b = {k: tuple(t.shape) for k, t in ours.state_dict().items()}
     assert a == b
     assert sum(p.numel() for p in ours.parameters()) == 6638848
+
+
+def test_fold_attention_weights_algebra():
+    """Host logic of path (A): the folded matrices reproduce, head by head, the unfused chain
+    q = W_q x, q~ = W_k^T q, u = W_d^T q~, e = E q~ on the input side and
+    y = sum_h W_o,h W_v,h (fbar + W_d pbar + E^T abar + b_d) + b_o on the output side
+    (attention.py:54-70 with kv = features + Linear(PE) + view embedding)."""
+    from pixelsplat_amd.epipolar import fold_attention_weights
+
+    torch.manual_seed(0)
+    H, dh, c, d, P, ov, d_out = 3, 5, 8, 6, 4, 2, 7
+    wq, wkv = torch.randn(H * dh, d), torch.randn(2 * H * dh, c)
+    wo, bo = torch.randn(d_out, H * dh), torch.randn(d_out)
+    dw, db, ve = torch.randn(c, P), torch.randn(c), torch.randn(ov, c)
+    for emb in (ve, None):
+        w_in, w_o_t, bias = fold_attention_weights(w_q=wq, w_kv=wkv, w_out=wo, b_out=bo, heads=H,
+                                                   depth_w=dw, depth_b=db, view_emb=emb)
+        lh = w_in.shape[0] // H
+        assert lh % 4 == 0 and w_o_t.shape == (H * lh, d_out)
+        x = torch.randn(d)
+        wk = wkv[:H * dh].reshape(H, dh, c)
+        wv = wkv[H * dh:].reshape(H, dh, c)
+        fb, pb, ab = torch.randn(H, c), torch.randn(H, P), torch.randn(H, ov)
+        fused = torch.zeros(H * lh)
+        ref = bo.clone()
+        for h in range(H):
+            qt = wk[h].T @ (wq.reshape(H, dh, d)[h] @ x)
+            row = w_in[h * lh:(h + 1) * lh] @ x
+            assert torch.allclose(row[:c], qt, atol=1e-4)
+            assert torch.allclose(row[c:c + P], dw.T @ qt, atol=1e-4)
+            if emb is not None:
+                assert torch.allclose(row[c + P:c + P + ov], ve @ qt, atol=1e-4)
+            fused[h * lh:h * lh + c] = fb[h]
+            fused[h * lh + c:h * lh + c + P] = pb[h]
+            ctxv = fb[h] + dw @ pb[h] + db
+            if emb is not None:
+                fused[h * lh + c + P:h * lh + c + P + ov] = ab[h]
+                ctxv = ctxv + ve.T @ ab[h]
+            ref += wo.reshape(d_out, H, dh)[:, h] @ (wv[h] @ ctxv)
+        assert torch.allclose(fused @ w_o_t + bias, ref, atol=1e-3)
