@@ -338,10 +338,11 @@ __device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, 
                                            const float* __restrict__ qrow, int hs_q,
                                            const float* __restrict__ urow, int hs_u,
                                            QueryRegs& Q) {
-  for (int hh = 0; hh < k.H; ++hh)
+  for (int hh = 0; hh < kMaxHeads; ++hh)      // absent heads are zero rows: no per-head branches
     for (int i = lane * 4; i < dm.c; i += kWave * 4)
       *reinterpret_cast<float4*>(k.qS + hh * dm.c + i) =
-          *reinterpret_cast<const float4*>(qrow + hh * hs_q + i);
+          hh < k.H ? *reinterpret_cast<const float4*>(qrow + hh * hs_q + i)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
   const int j = lane & 7;
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
@@ -371,10 +372,8 @@ __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k
       const float4 f = *reinterpret_cast<const float4*>(frow + ch);
 #pragma unroll
       for (int hh = 0; hh < kMaxHeads; ++hh) {
-        if (hh < k.H) {
-          const float4 q = *reinterpret_cast<const float4*>(k.qS + hh * dm.c + ch);
-          acc[hh] = fmaf(q.w, f.w, fmaf(q.z, f.z, fmaf(q.y, f.y, fmaf(q.x, f.x, acc[hh]))));
-        }
+        const float4 q = *reinterpret_cast<const float4*>(k.qS + hh * dm.c + ch);
+        acc[hh] = fmaf(q.w, f.w, fmaf(q.z, f.z, fmaf(q.y, f.y, fmaf(q.x, f.x, acc[hh]))));
       }
     }
   }
@@ -759,8 +758,11 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
 #pragma unroll
         for (int hh = 0; hh < kMaxHeads; ++hh) {
           const size_t rowh = ray * H + (hh < H ? hh : 0);
-          x.av[hh] = attn[rowh * T + si * ovn + ov];
-          x.dv[hh] = ds[rowh * T + si * ovn + ov];
+          // absent heads (hh >= H) get zero coefficients: the sample loop below has no
+          // per-head branches
+          const float a_ = attn[rowh * T + si * ovn + ov], d_ = ds[rowh * T + si * ovn + ov];
+          x.av[hh] = hh < H ? a_ : 0.f;
+          x.dv[hh] = hh < H ? d_ : 0.f;
           const int hs = hh < H ? hh : 0;
           load_cpl<CPL>(dfbar + ray * dm.ld_f + hs * dm.hs_f + cl, x.gq[hh]);
           load_cpl<CPL>(qt + ray * dm.ld_q + hs * dm.hs_q + cl, x.qq[hh]);
@@ -797,12 +799,10 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
           for (int i = 0; i < CPL; ++i) df[i] = 0.f;
 #pragma unroll
           for (int hh = 0; hh < kMaxHeads; ++hh) {
-            if (hh < H) {
-              const float a = lane_bcast(cur.av[hh], tl), d = lane_bcast(cur.dv[hh], tl);
+            const float a = lane_bcast(cur.av[hh], tl), d = lane_bcast(cur.dv[hh], tl);
 #pragma unroll
-              for (int i = 0; i < CPL; ++i)
-                df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
-            }
+            for (int i = 0; i < CPL; ++i)
+              df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
           }
           // four distinct pixels (or the dummy): reads first, then the writes
           V* dst[4]; V val[4];
