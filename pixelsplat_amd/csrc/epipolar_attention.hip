@@ -693,6 +693,8 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
   const int cl = lane_c ? c0 : 0;
   const int tile_floats = TS * TS * dm.c + max(dm.c, kWave * CPL);   // + dummy slots
   float* tile = tiles + (size_t)wv * tile_floats;
+  float* lane_base = tile + (lane_c ? 0 : TS * TS * dm.c) + c0;
+  const int lane_mul = lane_c ? 1 : 0;
   for (int i = lane; i < tile_floats; i += kWave) tile[i] = 0.f;
   wave_lds_sync();
 
@@ -808,8 +810,8 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
           V* dst[4]; V val[4];
 #pragma unroll
           for (int cr = 0; cr < 4; ++cr) {
-            const int o = lane_bcast_i(off[cr], tl);
-            dst[cr] = reinterpret_cast<V*>(tile + (lane_c ? o : TS * TS * dm.c) + c0);
+            // lanes past the last channel: multiplier 0 and a base inside the dummy slots
+            dst[cr] = reinterpret_cast<V*>(lane_base + lane_bcast_i(off[cr], tl) * lane_mul);
             val[cr] = *dst[cr];
           }
 #pragma unroll
