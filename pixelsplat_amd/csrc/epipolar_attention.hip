@@ -41,17 +41,6 @@ __device__ __forceinline__ void wave_sum4_to_lane63(float& a, float& b, float& c
 }
 #undef PS_DPP4
 
-__device__ __forceinline__ float wave_max_all(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum_all(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 struct Corner { int x0, y0; float wx, wy; };
 
 // grid_sample(bilinear, zeros, align_corners=False) addressing of normalised (x, y) in [0,1]

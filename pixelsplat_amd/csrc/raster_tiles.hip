@@ -264,36 +264,6 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
 // ------------------------------------------------------------------------------------
 // backward: walk the tile's bin back to front from the last contributor
 // ------------------------------------------------------------------------------------
-// Wave64 sums by DPP, nine values at a time: one fused shift+add (v_add_f32_dpp) per value
-// per step, six steps, totals land in lane 63.  The nine chains are interleaved so two DPP
-// ops on the same register are always >= 9 instructions apart (the VALU-write -> DPP-read
-// hazard needs 2 wait states and hipcc pads nothing inside an asm block).
-#define PS_DPP_STEP(ctrl)                                   \
-  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                     \
-  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                     \
-  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                     \
-  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                     \
-  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                     \
-  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                     \
-  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                     \
-  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"                     \
-  "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
-__device__ __forceinline__ void wave_sum9_to_lane63(float& a, float& b, float& c, float& d,
-                                                    float& e, float& f, float& g, float& h,
-                                                    float& i) {
-  asm volatile(
-      "s_nop 1\n"
-      PS_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-      PS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-      PS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-      PS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")   // lane 15 of a row = row total
-      PS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")              // rows 1,3 += row 0,2 totals
-      PS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")              // lane 63 = wave total
-      "s_nop 1\n"
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
-}
-#undef PS_DPP_STEP
-
 // Nine wave64 sums with the gfx950 lane-swap instructions.  v_permlane32_swap exchanges the
 // upper half of one register with the lower half of another, so ONE swap + ONE add folds two
 // values from 64 to 32 lanes each (a butterfly step that halves the number of live
