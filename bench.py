@@ -188,6 +188,7 @@ def main():
     tgt_img = target.reshape(V, 3, *hw).to(dev)
 
     # ---- path (A): paper encoder config (config/model/encoder/epipolar.yaml) ----
+    from pixelsplat_amd.epipolar import FeatureGradBatch
     from pixelsplat_amd.encoder.epipolar_transformer import (EpipolarTransformer,
                                                              EpipolarTransformerCfg,
                                                              ImageSelfAttentionCfg)
@@ -210,8 +211,9 @@ def main():
         geo = et.epipolar_sampler.geometry(c_ext, c_intr, c_near, c_far, (hA, wA))
         x = feat.reshape(-1, 1, d_feat)
         folds = et.fold_layers()
+        grad_batch = FeatureGradBatch()
         for (attn, _ff), folded in zip(et.transformer.layers, folds):
-            x = et.fused_layer(attn, x, feat, geo, folded=folded) + x
+            x = et.fused_layer(attn, x, feat, geo, folded=folded, batch=grad_batch) + x
         return x.square().mean()
 
     def path_b():

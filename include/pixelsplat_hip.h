@@ -252,6 +252,16 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap
                                    float* dfmap,
                                    uint32_t* ray_boxes, void* stream);
 
+/* Feature-map gradient of n_layers (1 or 2) attention layers that share the geometry, in ONE
+ * scatter pass: dfmap = sum over layers of the gradient ps_epipolar_attention_backward would
+ * write for that layer (call that function with dfmap = NULL and hand its ds here).  qt, attn,
+ * dfbar, ds: arrays of n_layers device pointers, laid out as in the descriptor. */
+int ps_epipolar_feature_grad(const PsEpipolarDesc* desc, int32_t n_layers,
+                             const float* xy_sample, const uint8_t* flags,
+                             const float* const* qt, const float* const* attn,
+                             const float* const* dfbar, const float* const* ds, float* dfmap,
+                             uint32_t* ray_boxes, void* stream);
+
 /* w2c[i] = c2w[i]^-1 (4x4) and k_inv[i] = k[i]^-1 (3x3) for n cameras, one launch, no host
  * sync (replaces the sampler's torch.linalg.inv calls: src/geometry/epipolar_lines.py:167,
  * src/geometry/projection.py:84). */

@@ -653,13 +653,24 @@ __device__ __forceinline__ int lane_bcast_i(int v, int lane) {
 
 constexpr int kDfWaves = 4;   // waves per tile, each with a private copy (rays interleaved)
 constexpr int kDfChunk = 2048; // rays culled per pass (bounds the per-wave hit list)
+constexpr int kMaxFgradLayers = 2;
 
-template <int CPL, int TS>
+// The attention layers of one encoder share the geometry (same samples, same features): their
+// feature-map gradients differ only in the per-sample coefficients, so NL layers are
+// scattered in ONE pass -- the cull, the corner records and the LDS read-modify-writes are
+// paid once, only the coefficient rows and the FMAs that build df scale with NL.
+struct FgradLayers {
+  const float* attn[kMaxFgradLayers];
+  const float* ds[kMaxFgradLayers];
+  const float* dfbar[kMaxFgradLayers];
+  const float* qt[kMaxFgradLayers];
+};
+
+template <int CPL, int TS, int NL>
 __global__ void __launch_bounds__(kDfWaves* kWave)
 epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
-                      const uint32_t* __restrict__ boxes, const float* __restrict__ attn,
-                      const float* __restrict__ ds, const float* __restrict__ dfbar,
-                      const float* __restrict__ qt, float* __restrict__ dfmap) {
+                      const uint32_t* __restrict__ boxes, FgradLayers L,
+                      float* __restrict__ dfmap) {
   extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][TS*TS pixels + dummy][c]
   using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
@@ -693,11 +704,17 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
                    (size_t)wv * (kDfChunk / kDfWaves);
   const int ngroups = (dm.s + kWave - 1) / kWave;                // 1 when s <= 64
 
-  struct RayRegs {
+  // per-item registers: sample positions and coefficients (lanes <-> samples) are prefetched
+  // one item ahead; the coefficient rows (lanes <-> channels) too when there is one layer,
+  // with two they are loaded at the start of the item to stay under 128 VGPRs
+  struct Coef {
     float2 p;
-    float av[kMaxHeads], dv[kMaxHeads];
-    float gq[kMaxHeads][CPL], qq[kMaxHeads][CPL];
+    float av[NL][kMaxHeads], dv[NL][kMaxHeads];
   };
+  struct Rows {
+    float gq[NL][kMaxHeads][CPL], qq[NL][kMaxHeads][CPL];
+  };
+  constexpr bool kPrefetchRows = NL == 1;
 
   for (int v = 0; v < dm.v; ++v) {
     if (v == sv) continue;
@@ -741,30 +758,45 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
       if (count == 0) continue;
       // 2. walk the list; the loads of item i+1 are in flight while item i is processed
       //    (a matched ray costs two dependent global-load latencies otherwise)
-      auto fetch = [&](int item, RayRegs& x) {
+      auto fetch_coef = [&](int item, Coef& x) {
         const int rr = chunk0 + list[item / ngroups];
         const int si = min((item % ngroups) * kWave + lane, dm.s - 1);
         const size_t ray = bv * R + rr;
         x.p = *reinterpret_cast<const float2*>(xy + 2 * ((ro0 + rr) * dm.s + si));
 #pragma unroll
-        for (int hh = 0; hh < kMaxHeads; ++hh) {
-          const size_t rowh = ray * H + (hh < H ? hh : 0);
-          // absent heads (hh >= H) get zero coefficients: the sample loop below has no
-          // per-head branches
-          const float a_ = attn[rowh * T + si * ovn + ov], d_ = ds[rowh * T + si * ovn + ov];
-          x.av[hh] = hh < H ? a_ : 0.f;
-          x.dv[hh] = hh < H ? d_ : 0.f;
-          const int hs = hh < H ? hh : 0;
-          load_cpl<CPL>(dfbar + ray * dm.ld_f + hs * dm.hs_f + cl, x.gq[hh]);
-          load_cpl<CPL>(qt + ray * dm.ld_q + hs * dm.hs_q + cl, x.qq[hh]);
-        }
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int hh = 0; hh < kMaxHeads; ++hh) {
+            const size_t rowh = ray * H + (hh < H ? hh : 0);
+            // absent heads (hh >= H) get zero coefficients: the sample loop below has no
+            // per-head branches
+            const float a_ = L.attn[l][rowh * T + si * ovn + ov];
+            const float d_ = L.ds[l][rowh * T + si * ovn + ov];
+            x.av[l][hh] = hh < H ? a_ : 0.f;
+            x.dv[l][hh] = hh < H ? d_ : 0.f;
+          }
+      };
+      auto fetch_rows = [&](int item, Rows& x) {
+        const size_t ray = bv * R + chunk0 + list[item / ngroups];
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int hh = 0; hh < kMaxHeads; ++hh) {
+            const int hs = hh < H ? hh : 0;
+            load_cpl<CPL>(L.dfbar[l] + ray * dm.ld_f + hs * dm.hs_f + cl, x.gq[l][hh]);
+            load_cpl<CPL>(L.qt[l] + ray * dm.ld_q + hs * dm.hs_q + cl, x.qq[l][hh]);
+          }
       };
       const int n_items = count * ngroups;
-      RayRegs cur;
-      fetch(0, cur);
+      Coef cur;
+      Rows rows, rows_nxt;
+      fetch_coef(0, cur);
+      if (kPrefetchRows) fetch_rows(0, rows);
       for (int item = 0; item < n_items; ++item) {
-        RayRegs nxt;
-        fetch(min(item + 1, n_items - 1), nxt);
+        Coef nxt;
+        if (!kPrefetchRows) fetch_rows(item, rows);
+        fetch_coef(min(item + 1, n_items - 1), nxt);
+        if (kPrefetchRows) fetch_rows(min(item + 1, n_items - 1), rows_nxt);
         // lanes <-> samples: corner records relative to this tile
         const bool tok = (item % ngroups) * kWave + lane < dm.s;
         const Corner kq = corner_of(cur.p.x, cur.p.y, dm.w, dm.h);
@@ -789,12 +821,14 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
 #pragma unroll
           for (int i = 0; i < CPL; ++i) df[i] = 0.f;
 #pragma unroll
-          for (int hh = 0; hh < kMaxHeads; ++hh) {
-            const float a = lane_bcast(cur.av[hh], tl), d = lane_bcast(cur.dv[hh], tl);
+          for (int l = 0; l < NL; ++l)
 #pragma unroll
-            for (int i = 0; i < CPL; ++i)
-              df[i] = fmaf(a, cur.gq[hh][i], fmaf(d, cur.qq[hh][i], df[i]));
-          }
+            for (int hh = 0; hh < kMaxHeads; ++hh) {
+              const float a = lane_bcast(cur.av[l][hh], tl), d = lane_bcast(cur.dv[l][hh], tl);
+#pragma unroll
+              for (int i = 0; i < CPL; ++i)
+                df[i] = fmaf(a, rows.gq[l][hh][i], fmaf(d, rows.qq[l][hh][i], df[i]));
+            }
           // four distinct pixels (or the dummy): reads first, then the writes
           V* dst[4]; V val[4];
 #pragma unroll
@@ -813,6 +847,7 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
           }
         }
         cur = nxt;
+        if (kPrefetchRows) rows = rows_nxt;
       }
       wave_lds_sync();
     }
@@ -910,29 +945,38 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
   return PS_OK;
 }
 
-int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint8_t* flags,
-                                 const float* qt, const float* attn, const float* dfbar,
-                                 const float* ds, float* dfmap, uint32_t* boxes, hipStream_t st) {
+int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* xy,
+                                 const uint8_t* flags, const float* const* qt,
+                                 const float* const* attn, const float* const* dfbar,
+                                 const float* const* ds, float* dfmap, uint32_t* boxes,
+                                 hipStream_t st) {
   if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
-  {
-    if (boxes == nullptr || dm.w > 255 || dm.h > 255) return PS_ERR_BAD_ARG;
-    const size_t n_ro = (size_t)dm.b * dm.v * dm.h * dm.w * (dm.v - 1);
-    hipLaunchKernelGGL(epipolar_ray_box_kernel, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
-                       0, st, dm, xy, flags, boxes);
-    constexpr int TS = 4;
-    const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
-    const int n_work = dm.b * dm.v * tiles;
-    dim3 g2((unsigned)((n_work + 7) / 8 * 8)), b2(kDfWaves * kWave);
-    const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
-    const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
-    const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
-#define PS_DF(CPL)                                                                              \
-  hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS>), g2, b2, sm2, st, dm, n_work, xy, boxes,  \
-                     attn,                                                                      \
-                     ds, dfbar, qt, dfmap)
-    if (dm.c <= 64) PS_DF(1); else if (dm.c <= 128) PS_DF(2); else PS_DF(4);
-#undef PS_DF
+  if (n_layers < 1 || n_layers > kMaxFgradLayers) return PS_ERR_UNSUPPORTED;
+  if (boxes == nullptr || dm.w > 255 || dm.h > 255) return PS_ERR_BAD_ARG;
+  FgradLayers L;
+  for (int l = 0; l < kMaxFgradLayers; ++l) {
+    const int s = l < n_layers ? l : 0;
+    L.attn[l] = attn[s]; L.ds[l] = ds[s]; L.dfbar[l] = dfbar[s]; L.qt[l] = qt[s];
+    if (!L.attn[l] || !L.ds[l] || !L.dfbar[l] || !L.qt[l]) return PS_ERR_BAD_ARG;
   }
+  const size_t n_ro = (size_t)dm.b * dm.v * dm.h * dm.w * (dm.v - 1);
+  hipLaunchKernelGGL(epipolar_ray_box_kernel, dim3((unsigned)((n_ro + 255) / 256)), dim3(256), 0,
+                     st, dm, xy, flags, boxes);
+  constexpr int TS = 4;
+  const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
+  const int n_work = dm.b * dm.v * tiles;
+  dim3 g2((unsigned)((n_work + 7) / 8 * 8)), b2(kDfWaves * kWave);
+  const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
+  const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
+  const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
+#define PS_DF(CPL, NL)                                                                          \
+  hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS, NL>), g2, b2, sm2, st, dm, n_work, xy,     \
+                     boxes, L, dfmap)
+#define PS_DFN(CPL)                                                                             \
+  do { if (n_layers == 1) PS_DF(CPL, 1); else PS_DF(CPL, 2); } while (0)
+  if (dm.c <= 64) PS_DFN(1); else if (dm.c <= 128) PS_DFN(2); else PS_DFN(4);
+#undef PS_DFN
+#undef PS_DF
   return PS_OK;
 }
 

@@ -317,10 +317,24 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
   }
   if (dfmap) {
     Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
-    if (int rc = launch_epipolar_feature_grad(to_dims(d), xy_sample, flags, qt, attn, dfbar, ds,
-                                              dfmap, ray_boxes, (hipStream_t)stream))
+    if (int rc = launch_epipolar_feature_grad(to_dims(d), 1, xy_sample, flags, &qt, &attn, &dfbar,
+                                              &ds, dfmap, ray_boxes, (hipStream_t)stream))
       return rc;
   }
+  return check_launch();
+}
+
+int ps_epipolar_feature_grad(const PsEpipolarDesc* d, int32_t n_layers, const float* xy_sample,
+                             const uint8_t* flags, const float* const* qt,
+                             const float* const* attn, const float* const* dfbar,
+                             const float* const* ds, float* dfmap, uint32_t* ray_boxes,
+                             void* stream) {
+  if (!epi_ok(d) || !xy_sample || !flags || !qt || !attn || !dfbar || !ds || !dfmap || !ray_boxes)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
+  if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn,
+                                            dfbar, ds, dfmap, ray_boxes, (hipStream_t)stream))
+    return rc;
   return check_launch();
 }
 

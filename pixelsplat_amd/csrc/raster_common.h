@@ -162,10 +162,11 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                                   const float* abar, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
                                   float* de, float* ds, hipStream_t st);
-int launch_epipolar_feature_grad(const AttnDims& dm, const float* xy, const uint8_t* flags,
-                                 const float* qt, const float* attn, const float* dfbar,
-                                 const float* ds, float* dfmap, uint32_t* boxes, hipStream_t st);
-
+int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* xy,
+                                 const uint8_t* flags, const float* const* qt,
+                                 const float* const* attn, const float* const* dfbar,
+                                 const float* const* ds, float* dfmap, uint32_t* boxes,
+                                 hipStream_t st);
 void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
                            hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);

@@ -19,7 +19,8 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from ..epipolar import fold_attention_weights, fused_cross_attention, gather_features
+from ..epipolar import (FeatureGradBatch, fold_attention_weights, fused_cross_attention,
+                        gather_features)
 from .epipolar_sampler import EpipolarSampler, EpipolarSampling
 from .transformer import Transformer
 
@@ -173,11 +174,12 @@ class EpipolarTransformer(nn.Module):
         return folds
 
     def fused_layer(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None,
-                    folded=None) -> Tensor:
+                    folded=None, batch=None) -> Tensor:
         """PreNorm(Attention)(x, z=kv) (pre_norm.py:34-35, attention.py:54-70) on the HIP path;
         `attn` is one `layer[0]` of `self.transformer.layers`, fmap is channels-last."""
         return fused_cross_attention(attn.norm(x), fmap, geo, octaves=self.cfg.num_octaves,
-                                     folded=folded, **self._layer_weights(attn, view_emb))
+                                     folded=folded, batch=batch,
+                                     **self._layer_weights(attn, view_emb))
 
     def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor, materialize_sampling: bool = False,
@@ -207,6 +209,7 @@ class EpipolarTransformer(nn.Module):
         x = fmap.reshape(b * v * h * w, 1, c)
         kv = None
         folds = self.fold_layers(view_emb) if features.is_cuda else [None] * len(self.transformer.layers)
+        grad_batch = FeatureGradBatch()     # the layers' feature-map gradients share one scatter
         for (attn, ff), folded in zip(self.transformer.layers, folds):
             a = attn.fn
             if len(a.attend._forward_hooks) > 0:
@@ -217,7 +220,7 @@ class EpipolarTransformer(nn.Module):
                     kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
                 y = attn(x, z=kv)
             else:
-                y = self.fused_layer(attn, x, fmap, geo, view_emb, folded)
+                y = self.fused_layer(attn, x, fmap, geo, view_emb, folded, grad_batch)
             x = y + x
             x = ff(x, b=b, v=v, h=h, w=w) + x
         features = x.reshape(b, v, h, w, c).permute(0, 1, 4, 2, 3)

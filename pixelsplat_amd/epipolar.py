@@ -141,6 +141,47 @@ def _pad4(n: int) -> int:
     return (n + 3) & ~3
 
 
+class FeatureGradBatch:
+    """Defers the feature-map gradients of attention layers that share one geometry and one
+    feature map (the layers of an EpipolarTransformer) so that they are scattered in ONE pass
+    (ps_epipolar_feature_grad).  Layers register in forward order; autograd runs their
+    backward in reverse, each parks its coefficients here, and the first-registered layer --
+    whose backward is necessarily the last -- flushes and returns the summed gradient.  One
+    batch per forward pass; the layers must be chained (each feeds the next), as in
+    Transformer.forward (transformer.py:67-71)."""
+
+    MAX_PER_LAUNCH = 2
+
+    def __init__(self):
+        self.registered = 0
+        self.pending = []
+
+    def register(self) -> int:
+        if self.pending:
+            raise RuntimeError("FeatureGradBatch reused while gradients are still parked")
+        self.registered += 1
+        return self.registered - 1
+
+    def park(self, qin, attn, dout, ds):
+        self.pending.append((qin, attn, dout, ds))
+
+    def flush(self, desc, fmap, xy, flags, c):
+        lib = _lib.load()
+        total = None
+        boxes = torch.empty((flags.numel(),), dtype=torch.int32, device=fmap.device)
+        while self.pending:
+            group, self.pending = (self.pending[:self.MAX_PER_LAUNCH],
+                                   self.pending[self.MAX_PER_LAUNCH:])
+            n = len(group)
+            arr = lambda k, off=0: (C.c_void_p * n)(*[t[k].data_ptr() + 4 * off for t in group])
+            dfmap = torch.empty_like(fmap)
+            _lib.check(lib.ps_epipolar_feature_grad(
+                C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
+                _p(dfmap), _p(boxes), _stream()), "ps_epipolar_feature_grad")
+            total = dfmap if total is None else total + dfmap
+        return total
+
+
 class _FusedEpipolarAttention(torch.autograd.Function):
     """(fmap, qin) -> (out, attn); see csrc/epipolar_attention.hip.
 
@@ -163,7 +204,7 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         return d, lh
 
     @staticmethod
-    def forward(ctx, dims, scale, has_e, fmap, xy, flags, rd, qin):
+    def forward(ctx, dims, scale, has_e, fmap, xy, flags, rd, qin, batch=None):
         lib = _lib.load()
         b, v, h, w, s, c, heads, octaves = dims
         R, T, P = b * v * h * w, s * (v - 1), 2 * octaves
@@ -180,6 +221,8 @@ class _FusedEpipolarAttention(torch.autograd.Function):
             col(qin, c + P) if has_e else None, C.c_float(scale), col(out, 0), col(out, c),
             col(out, c + P), _p(attn), _stream()), "ps_epipolar_attention_forward")
         ctx.dims, ctx.scale, ctx.has_e, ctx.padded = dims, scale, has_e, padded
+        ctx.batch = batch
+        ctx.batch_index = batch.register() if batch is not None else -1
         ctx.save_for_backward(fmap, xy, flags, rd, qin, attn, out)
         ctx.mark_non_differentiable(attn)
         return out, attn
@@ -196,7 +239,8 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         dqin = (torch.zeros if ctx.padded else torch.empty)((R, heads * lh), **f32)
         ds = torch.empty((R, heads, T), **f32)
         dfmap = boxes = None
-        if ctx.needs_input_grad[3]:
+        deferred = ctx.batch is not None and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[3] and not deferred:
             dfmap = torch.empty_like(fmap)
             boxes = torch.empty((R * ov,), dtype=torch.int32, device=fmap.device)
         col = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
@@ -207,7 +251,12 @@ class _FusedEpipolarAttention(torch.autograd.Function):
             col(dout, 0), col(dout, c), col(dout, c + P) if ctx.has_e else None,
             C.c_float(ctx.scale), col(dqin, 0), col(dqin, c), de, _p(ds), _p(dfmap), _p(boxes),
             _stream()), "ps_epipolar_attention_backward")
-        return (None, None, None, dfmap, None, None, None, dqin)
+        if deferred:
+            # parked until the first layer of the batch (whose backward runs last) flushes
+            ctx.batch.park(qin, attn, dout, ds)
+            if ctx.batch_index == 0:
+                dfmap = ctx.batch.flush(d, fmap, xy, flags, c)
+        return (None, None, None, dfmap, None, None, None, dqin, None)
 
 
 def fold_attention_weights(*, w_q: Tensor, w_kv: Tensor, w_out: Tensor, b_out: Tensor | None,
@@ -250,14 +299,16 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
                           w_kv: Tensor, w_out: Tensor, b_out: Tensor | None, heads: int,
                           depth_w: Tensor, depth_b: Tensor, octaves: int,
                           view_emb: Tensor | None = None, return_attn: bool = False,
-                          folded=None):
+                          folded=None, batch: FeatureGradBatch | None = None):
     """Attention(x, z=kv) of the reference (attention.py:54-70) for kv = gathered features +
     Linear(PE(relative disparity)) [+ view embedding], without ever forming kv.
 
     x [R, 1, d] (already layer-normed), fmap_nhwc [b, v, h, w, c]; w_q [inner, d],
     w_kv [2*inner, c], w_out [d, inner]; depth_w [c, 2*octaves], depth_b [c];
     view_emb [v-1, c] (already permuted) or None; `folded` = fold_attention_weights(...) of
-    the same weights when the caller computed it ahead.  Returns [R, 1, d] (and attn [R,H,1,T])."""
+    the same weights when the caller computed it ahead; `batch` = a FeatureGradBatch shared by
+    the chained layers of one forward pass (their feature-map gradients are then scattered
+    together).  Returns [R, 1, d] (and attn [R,H,1,T])."""
     b, v, h, w, c = fmap_nhwc.shape
     s = geo.xy_sample.shape[-2]
     dh = w_q.shape[0] // heads
@@ -272,7 +323,7 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None)              # heads x [q~ | u | e]
     fused, attn = _FusedEpipolarAttention.apply(
         dims, float(dh) ** -0.5, has_e, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample,
-        geo.flags, geo.rel_disparity, qin)
+        geo.flags, geo.rel_disparity, qin, batch)
     out = _RayLinear.apply(fused, w_o_t.T, bias).reshape(R, 1, d_out)
     if return_attn:
         return out, attn.reshape(R, heads, 1, -1)

@@ -271,3 +271,43 @@ def test_gemm_tn_splitk(gpu_device, m, n, k):
     c3 = gemm_tn(wide[:, 4:4 + m], b.to(gpu_device))
     ref3 = wide[:, 4:4 + m].cpu().double().T @ b.double()
     assert (c3.cpu().double() - ref3).abs().max().item() < 2e-6 * k ** 0.5 * 4
+
+
+@pytest.mark.parametrize("v,c", [(2, 128), (3, 32)])
+def test_feature_grad_batch_matches_per_layer(gpu_device, v, c):
+    """Two chained attention layers on one feature map: the deferred one-pass scatter of both
+    layers' feature-map gradients (FeatureGradBatch / ps_epipolar_feature_grad, n_layers = 2)
+    equals the sum of the per-layer scatters, for every gradient."""
+    from pixelsplat_amd.epipolar import FeatureGradBatch, fused_cross_attention, sample_geometry
+
+    torch.manual_seed(1)
+    b, h, w, s, heads, dh = 2, 9, 7, 12, 4, 8
+    dev = gpu_device
+    ctx = _cams(b, v, 5)
+    geo = sample_geometry(ctx.extrinsics.to(dev), ctx.intrinsics.to(dev), ctx.near.to(dev),
+                          ctx.far.to(dev), (h, w), s)
+    inner = heads * dh
+    mk = lambda *shape, sc=0.3: (torch.randn(*shape) * sc).to(dev)
+    layers = [dict(w_q=mk(inner, c), w_kv=mk(2 * inner, c), w_out=mk(c, inner), b_out=mk(c, sc=0.1),
+                   depth_w=mk(c, 20), depth_b=mk(c, sc=0.1),
+                   view_emb=(mk(v - 1, c) if v > 2 else None)) for _ in range(2)]
+    feat0 = torch.randn(b, v, h, w, c, device=dev)
+
+    def run(batched):
+        feat = feat0.clone().requires_grad_(True)
+        leaves = [{k: (t.clone().requires_grad_(True) if t is not None else None)
+                   for k, t in lay.items()} for lay in layers]
+        batch = FeatureGradBatch() if batched else None
+        x = feat.reshape(-1, 1, c)
+        for lay in leaves:
+            x = fused_cross_attention(torch.tanh(x), feat, geo, heads=heads, octaves=10,
+                                      batch=batch, **lay) + x
+        x.square().mean().backward()
+        grads = [feat.grad] + [t.grad for lay in leaves for t in lay.values() if t is not None]
+        return x.detach(), grads
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    assert torch.equal(y0, y1)
+    for a, bb in zip(g0, g1):
+        assert (a - bb).abs().max() <= 2e-6 * max(a.abs().max().item(), 1e-6)
