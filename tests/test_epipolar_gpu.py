@@ -311,3 +311,25 @@ def test_feature_grad_batch_matches_per_layer(gpu_device, v, c):
     assert torch.equal(y0, y1)
     for a, bb in zip(g0, g1):
         assert (a - bb).abs().max() <= 2e-6 * max(a.abs().max().item(), 1e-6)
+
+
+def test_invert_cameras(gpu_device):
+    """ps_invert_cameras (double-precision cofactors, one launch, no host sync) against
+    torch.linalg.inv in float64."""
+    import ctypes as C
+
+    from pixelsplat_amd import _lib
+
+    lib = _lib.load()
+    ctx = _cams(3, 3, 5)
+    c2w = ctx.extrinsics.reshape(-1, 4, 4).contiguous().to(gpu_device)
+    k = ctx.intrinsics.reshape(-1, 3, 3).contiguous().to(gpu_device)
+    w2c, k_inv = torch.empty_like(c2w), torch.empty_like(k)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.ps_invert_cameras(C.c_int32(c2w.shape[0]), p(c2w), p(k), p(w2c), p(k_inv),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "ps_invert_cameras")
+    ref_w = torch.linalg.inv(c2w.double().cpu())
+    ref_k = torch.linalg.inv(k.double().cpu())
+    assert (w2c.cpu().double() - ref_w).abs().max() < 1e-6 * ref_w.abs().max()
+    assert (k_inv.cpu().double() - ref_k).abs().max() < 1e-6 * ref_k.abs().max()
