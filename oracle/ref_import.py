@@ -16,6 +16,7 @@ from types import SimpleNamespace
 REF = os.environ.get("PIXELSPLAT_REFERENCE", "/root/reference")
 _SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_shim")
 _PKGS = ["src", "src.model", "src.model.encoder", "src.model.encoder.epipolar",
+         "src.model.encoder.common",
          "src.model.decoder", "src.model.transformer", "src.model.encodings", "src.geometry",
          "src.misc"]
 
@@ -57,4 +58,20 @@ def modules(num_context_views: int = 2) -> SimpleNamespace:
         tfm=imp("src.model.transformer.transformer"),
         pe=imp("src.model.encodings.positional_encoding"),
         pairings=imp("src.misc.heterogeneous_pairings"),
+    )
+
+
+def adapter_modules() -> SimpleNamespace:
+    """The reference's GaussianAdapter stack.  e3nn (absent, unpinned) is replaced by
+    oracle/ref_shim/e3nn, i.e. by oracle/adapter_ref.py's restatement of its two functions."""
+    setup(2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    imp = importlib.import_module
+    return SimpleNamespace(
+        adapter=imp("src.model.encoder.common.gaussian_adapter"),
+        gaussians=imp("src.model.encoder.common.gaussians"),
+        sh_rotation=imp("src.misc.sh_rotation"),
+        projection=imp("src.geometry.projection"),
     )

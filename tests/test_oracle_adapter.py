@@ -1,0 +1,65 @@
+"""CPU: oracle/adapter_ref.py against the golden vectors produced by the REAL reference
+GaussianAdapter (tests/golden/make_adapter_golden.py) and, for the e3nn part that cannot be
+pinned (e3nn absent and unpinned), the properties any correct Wigner-D must have."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import adapter_ref as A
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "adapter.npz")
+
+
+def _gold():
+    return {k: torch.from_numpy(v) if v.dtype != np.int64 else v for k, v in np.load(GOLD).items()}
+
+
+def test_restatement_matches_reference_golden():
+    g = _gold()
+    h, w = (int(x) for x in g["image_shape"])
+    leaves = {k: g[k].clone().requires_grad_(True)
+              for k in ("coordinates", "depths", "opacities", "raw_gaussians")}
+    ext = g["extrinsics"][:, :, None, None, None]
+    intr = g["intrinsics"][:, :, None, None, None]
+    o = A.adapter_forward(ext, intr, leaves["coordinates"], leaves["depths"], leaves["opacities"],
+                          leaves["raw_gaussians"], (h, w), 0.5, 15.0, 4)
+    outs = dict(means=o.means, covariances=o.covariances, harmonics=o.harmonics,
+                opacities_out=o.opacities, scales=o.scales, rotations=o.rotations)
+    for k, t in outs.items():
+        assert (t - g[k]).abs().max() <= 1e-6 * max(1.0, g[k].abs().max().item()), k
+    sum((outs[k] * g["w_" + k]).sum() for k in ("means", "covariances", "harmonics",
+                                                 "opacities_out")).backward()
+    for k, t in leaves.items():
+        ref = g["grad_" + k]
+        assert (t.grad - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_wigner_d_properties():
+    """What can be said about the e3nn restatement without e3nn: D^0 = 1, D^1 = R in e3nn's
+    (x, y, z) order, every D^l orthogonal and a group homomorphism, matrix_to_angles inverts
+    angles_to_matrix."""
+    torch.manual_seed(0)
+    a1 = [torch.rand(7, dtype=torch.float64) * 6 - 3 for _ in range(3)]
+    a2 = [torch.rand(7, dtype=torch.float64) * 6 - 3 for _ in range(3)]
+    r1, r2 = A.angles_to_matrix(*a1), A.angles_to_matrix(*a2)
+    assert (A.angles_to_matrix(*A.matrix_to_angles(r1)) - r1).abs().max() < 1e-12
+    assert (A.wigner_D(0, *a1) - 1).abs().max() < 1e-12
+    assert (A.wigner_D(1, *a1) - r1).abs().max() < 1e-12
+    for l in range(5):
+        d1, d2 = A.wigner_D(l, *a1), A.wigner_D(l, *a2)
+        eye = torch.eye(2 * l + 1, dtype=torch.float64)
+        assert (d1 @ d1.transpose(-1, -2) - eye).abs().max() < 1e-12
+        d12 = A.wigner_D(l, *A.matrix_to_angles(r1 @ r2))
+        assert (d12 - d1 @ d2).abs().max() < 1e-11
+
+
+def test_rotate_sh_degree_one_rotates_vectors():
+    """rotate_sh on the three l = 1 coefficients is the rotation itself (e3nn's l = 1 basis is
+    x, y, z), and the l = 0 coefficient is untouched."""
+    torch.manual_seed(1)
+    r = A.angles_to_matrix(*[torch.rand(4, dtype=torch.float64) * 6 - 3 for _ in range(3)])
+    sh = torch.randn(4, 25, dtype=torch.float64)
+    out = A.rotate_sh(sh, r)
+    assert torch.allclose(out[:, 0], sh[:, 0])
+    assert torch.allclose(out[:, 1:4], torch.einsum("nij,nj->ni", r, sh[:, 1:4]), atol=1e-12)
