@@ -252,6 +252,38 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* desc, const float* fmap
                                    float* dfmap,
                                    uint32_t* ray_boxes, void* stream);
 
+/* ---- Gaussian adapter: raw network outputs -> rasterizer inputs --------
+ * Replaces GaussianAdapter.forward and its autograd graph
+ * (src/model/encoder/common/gaussian_adapter.py:48-95, gaussians.py:8-41,
+ * src/geometry/projection.py:65-108, src/misc/sh_rotation.py:10-31 incl. the e3nn Wigner-D).
+ * Entries = (pixel, surface) pairs of a view, each with spp depth samples; Gaussian index
+ * g = (view * entries_per_view + entry) * spp + sample, i.e. the flattening of
+ * encoder_epipolar.py:197-214, so means / covariances / harmonics are directly the
+ * [S][G]... arrays of ps_raster_forward (PS_COV_33, PS_SH_G3K).
+ *   views        float[n_views][192]   per-view constants from ps_gaussian_adapter_views
+ *   coordinates  float[n_views][entries][2]   normalised image coordinates of the rays
+ *   depths       float[n_views][entries][spp]
+ *   raw          float[n_views][entries][7 + 3 (deg+1)^2]  scale(3) | quaternion xyzw(4) | SH
+ *   wigner_conj  double[164]: the fixed matrices P_1..P_4 with G_x = P G_y P^T on e3nn's real
+ *                harmonics (pixelsplat_amd/wigner.py)
+ * Opacities pass through unchanged and are not an argument. */
+#define PS_ADAPTER_VIEW_STRIDE 192
+int ps_gaussian_adapter_views(int32_t n_views, int32_t sh_degree, int32_t image_h, int32_t image_w,
+                              const float* extrinsics, const float* intrinsics,
+                              const double* wigner_conj, float* views, void* stream);
+int ps_gaussian_adapter_forward(int32_t n_views, int32_t entries_per_view, int32_t spp,
+                                int32_t sh_degree, float scale_min, float scale_max, float eps,
+                                const float* views, const float* coordinates, const float* depths,
+                                const float* raw, float* means, float* covariances,
+                                float* harmonics, void* stream);
+int ps_gaussian_adapter_backward(int32_t n_views, int32_t entries_per_view, int32_t spp,
+                                 int32_t sh_degree, float scale_min, float scale_max, float eps,
+                                 const float* views, const float* coordinates,
+                                 const float* depths, const float* raw, const float* d_means,
+                                 const float* d_covariances, const float* d_harmonics,
+                                 float* d_raw, float* d_depths, float* d_coordinates,
+                                 void* stream);
+
 /* Feature-map gradient of n_layers (1 or 2) attention layers that share the geometry, in ONE
  * scatter pass: dfmap = sum over layers of the gradient ps_epipolar_attention_backward would
  * write for that layer (call that function with dfmap = NULL and hand its ds here).  qt, attn,

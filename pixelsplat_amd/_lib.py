@@ -50,7 +50,8 @@ EXPORTS = [
     "ps_raster_forward_render", "ps_raster_backward",
     "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
     "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
-    "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad",
+    "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_gaussian_adapter_views",
+    "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
 ]
 
@@ -115,6 +116,12 @@ def load():
     lib.ps_epipolar_attention_backward.restype = C.c_int
     lib.ps_epipolar_feature_grad.argtypes = [pe, C.c_int32] + [vp] * 9
     lib.ps_epipolar_feature_grad.restype = C.c_int
+    lib.ps_gaussian_adapter_views.argtypes = [C.c_int32] * 4 + [vp] * 5
+    lib.ps_gaussian_adapter_views.restype = C.c_int
+    lib.ps_gaussian_adapter_forward.argtypes = [C.c_int32] * 4 + [C.c_float] * 3 + [vp] * 8
+    lib.ps_gaussian_adapter_forward.restype = C.c_int
+    lib.ps_gaussian_adapter_backward.argtypes = [C.c_int32] * 4 + [C.c_float] * 3 + [vp] * 11
+    lib.ps_gaussian_adapter_backward.restype = C.c_int
     lib.ps_invert_cameras.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
     lib.ps_invert_cameras.restype = C.c_int
     lib.ps_gemm_tn_workspace_bytes.argtypes = [C.c_int32] * 3

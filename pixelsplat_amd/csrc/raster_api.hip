@@ -12,12 +12,14 @@ namespace {
 
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
 enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET,
-             G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_GEMM_TN, G_COUNT };
+             G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_GEMM_TN, G_ADAPTER_FWD, G_ADAPTER_BWD,
+             G_COUNT };
 const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
                                     "tiles_backward", "preprocess_backward", "memset",
                                     "epipolar_geometry", "epipolar_attention_forward",
                                     "epipolar_attention_backward", "epipolar_feature_grad",
-                                    "gemm_tn_splitk"};
+                                    "gemm_tn_splitk", "gaussian_adapter_forward",
+                                    "gaussian_adapter_backward"};
 std::atomic<int> g_profile_on{0};
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
@@ -334,6 +336,54 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* d, int32_t n_layers, const fl
   Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
   if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn,
                                             dfbar, ds, dfmap, ray_boxes, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_gaussian_adapter_views(int32_t n_views, int32_t sh_degree, int32_t image_h, int32_t image_w,
+                              const float* extrinsics, const float* intrinsics,
+                              const double* wigner_conj, float* views, void* stream) {
+  if (n_views <= 0 || sh_degree < 0 || sh_degree > 4 || image_h <= 0 || image_w <= 0 ||
+      !extrinsics || !intrinsics || !wigner_conj || !views)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_ADAPTER_FWD, (hipStream_t)stream);
+  if (int rc = launch_adapter_views(n_views, sh_degree, image_h, image_w, extrinsics, intrinsics,
+                                    wigner_conj, views, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_gaussian_adapter_forward(int32_t n_views, int32_t entries_per_view, int32_t spp,
+                                int32_t sh_degree, float scale_min, float scale_max, float eps,
+                                const float* views, const float* coordinates, const float* depths,
+                                const float* raw, float* means, float* covariances,
+                                float* harmonics, void* stream) {
+  if (n_views <= 0 || entries_per_view <= 0 || spp <= 0 || !views || !coordinates || !depths ||
+      !raw || !means || !covariances || !harmonics)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_ADAPTER_FWD, (hipStream_t)stream);
+  if (int rc = launch_adapter_forward(n_views, entries_per_view, spp, sh_degree, scale_min,
+                                      scale_max, eps, views, coordinates, depths, raw, means,
+                                      covariances, harmonics, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_gaussian_adapter_backward(int32_t n_views, int32_t entries_per_view, int32_t spp,
+                                 int32_t sh_degree, float scale_min, float scale_max, float eps,
+                                 const float* views, const float* coordinates,
+                                 const float* depths, const float* raw, const float* d_means,
+                                 const float* d_covariances, const float* d_harmonics,
+                                 float* d_raw, float* d_depths, float* d_coordinates,
+                                 void* stream) {
+  if (n_views <= 0 || entries_per_view <= 0 || spp <= 0 || !views || !coordinates || !depths ||
+      !raw || !d_means || !d_covariances || !d_harmonics || !d_raw || !d_depths || !d_coordinates)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_ADAPTER_BWD, (hipStream_t)stream);
+  if (int rc = launch_adapter_backward(n_views, entries_per_view, spp, sh_degree, scale_min,
+                                       scale_max, eps, views, coordinates, depths, raw, d_means,
+                                       d_covariances, d_harmonics, d_raw, d_depths, d_coordinates,
+                                       (hipStream_t)stream))
     return rc;
   return check_launch();
 }

@@ -167,6 +167,18 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
                                  const float* const* attn, const float* const* dfbar,
                                  const float* const* ds, float* dfmap, uint32_t* boxes,
                                  hipStream_t st);
+int launch_adapter_views(int n_views, int sh_degree, int img_h, int img_w, const float* extrinsics,
+                         const float* intrinsics, const double* conj, float* views,
+                         hipStream_t st);
+int launch_adapter_forward(int n_views, int rp, int spp, int sh_degree, float smin, float smax,
+                           float eps, const float* views, const float* coords,
+                           const float* depths, const float* raw, float* means, float* cov,
+                           float* harmonics, hipStream_t st);
+int launch_adapter_backward(int n_views, int rp, int spp, int sh_degree, float smin, float smax,
+                            float eps, const float* views, const float* coords,
+                            const float* depths, const float* raw, const float* d_means,
+                            const float* d_cov, const float* d_harmonics, float* d_raw,
+                            float* d_depths, float* d_coords, hipStream_t st);
 void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
                            hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);

@@ -5,4 +5,5 @@ kernels of libpixelsplat_hip.so."""
 from .epipolar_sampler import EpipolarSampler, EpipolarSampling  # noqa: F401
 from .epipolar_transformer import (EpipolarTransformer, EpipolarTransformerCfg,  # noqa: F401
                                    ImageSelfAttentionCfg)
+from .gaussian_adapter import GaussianAdapter, GaussianAdapterCfg, Gaussians  # noqa: F401
 from .transformer import Attention, FeedForward, PreNorm, Transformer  # noqa: F401
