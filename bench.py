@@ -229,6 +229,25 @@ def main():
         loss = (path_a() if a else 0.0) + (path_b() if b_ else 0.0)
         loss.backward()
 
+    # ---- Gaussian adapter, timed on its own after the contract's region:
+    # the producer of the rasterizer's inputs at the same shape (b x 2 views x HxW rays x 3)
+    from pixelsplat_amd.encoder import GaussianAdapter, GaussianAdapterCfg
+    ga = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 4)).to(dev)
+    n_rays = hw[0] * hw[1]
+    ga_in = dict(
+        coordinates=torch.rand(b, 2, n_rays, 1, 1, 2, device=dev).requires_grad_(True),
+        depths=(torch.rand(b, 2, n_rays, 1, 3, device=dev) * 5 + 0.5).requires_grad_(True),
+        opacities=torch.rand(b, 2, n_rays, 1, 3, device=dev),
+        raw=torch.randn(b, 2, n_rays, 1, 1, 82, device=dev).requires_grad_(True))
+    ga_ext, ga_intr = c_ext[:, :, None, None, None], c_intr[:, :, None, None, None]
+
+    def step_adapter():
+        for t in ga_in.values():
+            t.grad = None
+        g_ = ga(ga_ext, ga_intr, ga_in["coordinates"], ga_in["depths"], ga_in["opacities"],
+                ga_in["raw"], hw)
+        (g_.means.sum() + g_.covariances.sum() + g_.harmonics.sum()).backward()
+
     def timed(fn, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -266,6 +285,8 @@ def main():
     # outside the contract's timed region: each path alone
     ms_b = timed(lambda: step(a=False), args.steps)
     ms_a = timed(lambda: step(b_=False), args.steps)
+    step_adapter()
+    ms_ga = timed(step_adapter, args.steps)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -329,6 +350,9 @@ def main():
                 "raster_only_ms_per_step": round(ms_b, 3),
                 "raster_only_views_per_s": round(V / ms_b * 1e3 * world, 1),
                 "epipolar_only_ms_per_step": round(ms_a, 3),
+                # next row of SURVEY.md 8(f): raw network outputs -> Gaussians, fwd + bwd incl.
+                # the three torch .sum() reductions of this probe; not part of `value`
+                "gaussian_adapter_only_ms_per_step": round(ms_ga, 3),
                 "epipolar_reference_equivalent_tflops": round(
                     3.0 * 2 * (2.0 * RA * (2 * d_feat * 512 + TA * d_feat * 1024 + 2 * 4 * TA * 128))
                     / (ms_a * 1e-3) / 1e12, 1),

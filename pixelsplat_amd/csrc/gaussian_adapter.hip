@@ -9,8 +9,10 @@
 // Outputs are written directly in the layouts ps_raster_forward consumes (PS_SH_G3K,
 // PS_COV_33), Gaussian index g = ((view * r + pixel) * srf + surface) * spp + sample.
 //
-// A wave owns 64 consecutive (pixel, surface) entries of one view.  Their raw vectors
-// (7 + 3K floats each, one contiguous 21 KB block at K = 25) are staged in LDS with coalesced
+// A wave owns 16 consecutive (pixel, surface) entries of one view (7.5 KB of LDS: 20 waves per
+// CU; with 64 entries the kernels ran at 5 waves per CU: forward 0.42 -> 0.31 ms, backward
+// 0.72 -> 0.46 ms).  Their raw vectors (7 + 3K floats each, one contiguous 5.2 KB block at
+// K = 25) are staged in LDS with coalesced
 // 16-byte loads; each lane rotates its SH coefficients in place in that slab; the harmonics of
 // the spp samples of a pixel are identical, so the slab is streamed out spp times into the
 // (again contiguous) output block.  Per-view constants -- c2w rotation, origin, K^-1, the
@@ -20,89 +22,93 @@
 namespace ps {
 
 constexpr int kViewStride = 192;   // floats per view block
+constexpr int kEntries = 16;       // (pixel, surface) entries per wave: LDS sets the occupancy
 constexpr int kViewRot = 0, kViewOrigin = 9, kViewKinv = 12, kViewMult = 21, kViewD = 24;
 __host__ __device__ constexpr int wigner_block(int l) {   // start of the (2l+1)^2 block
   return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 10 : l == 3 ? 35 : 84;
 }
 
 // ---------------------------------------------------------------------------------------
-// per-view constants (one thread per view, double precision)
+// per-view constants: one block per view, wave w builds the Wigner-D of degree w + 1 in LDS
+// (double precision; Z(t) has two entries per row, so only P Z(b) P^T costs a real product)
 // ---------------------------------------------------------------------------------------
-__device__ inline void z_rot(int l, double t, double* z /*[(2l+1)^2], zeroed*/) {
-  const int n = 2 * l + 1;
-  for (int i = 0; i < n * n; ++i) z[i] = 0.0;
-  z[l * n + l] = 1.0;
-  for (int m = 1; m <= l; ++m) {
-    const double c = cos(m * t), s = sin(m * t);
-    z[(l - m) * n + (l - m)] = c; z[(l - m) * n + (l + m)] = s;
-    z[(l + m) * n + (l - m)] = -s; z[(l + m) * n + (l + m)] = c;
-  }
-}
-__device__ inline void matmul_n(int n, const double* a, const double* b, bool b_transposed,
-                                double* out) {
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < n; ++k) s += a[i * n + k] * (b_transposed ? b[j * n + k] : b[k * n + j]);
-      out[i * n + j] = s;
-    }
-}
-
-__global__ void adapter_view_kernel(int n_views, int sh_degree, int img_h, int img_w,
-                                    const float* __restrict__ extrinsics,
-                                    const float* __restrict__ intrinsics,
-                                    const double* __restrict__ conj /*P_1..P_4*/,
-                                    float* __restrict__ views) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n_views) return;
+__global__ void __launch_bounds__(256)
+adapter_view_kernel(int n_views, int sh_degree, int img_h, int img_w,
+                    const float* __restrict__ extrinsics, const float* __restrict__ intrinsics,
+                    const double* __restrict__ conj /*P_1..P_4*/, float* __restrict__ views) {
+  __shared__ double ang[3];
+  __shared__ double buf[4][2][81];
+  const int v = blockIdx.x;
   const float* e = extrinsics + 16 * v;
   const float* k = intrinsics + 9 * v;
   float* out = views + (size_t)v * kViewStride;
-  double R[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) { R[3 * i + j] = e[4 * i + j]; out[kViewRot + 3 * i + j] = e[4 * i + j]; }
-  for (int i = 0; i < 3; ++i) out[kViewOrigin + i] = e[4 * i + 3];
-  {  // K^-1 (cofactors) and the scale multiplier 0.1 * sum(K[:2,:2]^-1 (1/w, 1/h))
-    double m[9], inv[9];
-    for (int i = 0; i < 9; ++i) m[i] = k[i];
-    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
-                 c02 = m[3] * m[7] - m[4] * m[6];
-    const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
-    inv[0] = c00 * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    inv[3] = c01 * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-    for (int i = 0; i < 9; ++i) out[kViewKinv + i] = (float)inv[i];
-    const double d2 = 1.0 / (m[0] * m[4] - m[1] * m[3]);
-    const double px = 1.0 / img_w, py = 1.0 / img_h;
-    const double mx = (m[4] * px - m[1] * py) * d2, my = (-m[3] * px + m[0] * py) * d2;
-    out[kViewMult] = (float)(0.1 * (mx + my));
+  if (threadIdx.x == 0) {
+    double R[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { R[3 * i + j] = e[4 * i + j]; out[kViewRot + 3 * i + j] = e[4 * i + j]; }
+    for (int i = 0; i < 3; ++i) out[kViewOrigin + i] = e[4 * i + 3];
+    {  // K^-1 (cofactors) and the scale multiplier 0.1 * sum(K[:2,:2]^-1 (1/w, 1/h))
+      double m[9], inv[9];
+      for (int i = 0; i < 9; ++i) m[i] = k[i];
+      const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
+                   c02 = m[3] * m[7] - m[4] * m[6];
+      const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+      inv[0] = c00 * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+      inv[3] = c01 * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+      inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+      for (int i = 0; i < 9; ++i) out[kViewKinv + i] = (float)inv[i];
+      const double d2 = 1.0 / (m[0] * m[4] - m[1] * m[3]);
+      const double px = 1.0 / img_w, py = 1.0 / img_h;
+      const double mx = (m[4] * px - m[1] * py) * d2, my = (-m[3] * px + m[0] * py) * d2;
+      out[kViewMult] = (float)(0.1 * (mx + my));
+    }
+    // e3nn.o3.matrix_to_angles: R = Y(alpha) X(beta) Y(gamma)
+    double x0 = R[1], x1 = R[4], x2 = R[7];               // R (0, 1, 0)
+    const double nx = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+    x0 /= nx; x1 /= nx; x2 /= nx;
+    x1 = fmin(1.0, fmax(-1.0, x1));
+    const double beta = acos(x1), alpha = atan2(x0, x2);
+    // first row of (Y(alpha) X(beta))^T R: column 0 of Y(a) X(b) is (cos a, 0, -sin a)
+    const double ca = cos(alpha), sa = sin(alpha);
+    const double gamma = atan2(ca * R[2] - sa * R[8], ca * R[0] - sa * R[6]);
+    ang[0] = alpha; ang[1] = beta; ang[2] = gamma;
+    out[kViewD] = 1.0f;
   }
-  // e3nn.o3.matrix_to_angles: R = Y(alpha) X(beta) Y(gamma)
-  double x0 = R[1], x1 = R[4], x2 = R[7];               // R (0, 1, 0)
-  const double nx = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-  x0 /= nx; x1 /= nx; x2 /= nx;
-  x1 = fmin(1.0, fmax(-1.0, x1));
-  const double beta = acos(x1), alpha = atan2(x0, x2);
-  // first row of (Y(alpha) X(beta))^T R
-  const double ca = cos(alpha), sa = sin(alpha);
-  // Y(a) X(b) column 0 = Y(a) (1, 0, 0) = (ca, 0, -sa): row 0 of the transpose
-  const double r00 = ca * R[0] - sa * R[6], r02 = ca * R[2] - sa * R[8];
-  const double gamma = atan2(r02, r00);
-  out[kViewD] = 1.0f;
-  double za[81], zb[81], zc[81], t1[81], t2[81];
+  __syncthreads();
+  const int l = (threadIdx.x >> 6) + 1, lane = threadIdx.x & 63;
+  const bool on = l <= sh_degree && l <= 4;
+  const int n = 2 * l + 1, nn = n * n;
   int off = 0;
-  for (int l = 1; l <= sh_degree && l <= 4; ++l) {
-    const int n = 2 * l + 1;
-    const double* P = conj + off;
-    off += n * n;
-    z_rot(l, alpha, za); z_rot(l, beta, zb); z_rot(l, gamma, zc);
-    matmul_n(n, za, P, false, t1);        // Z(a) P
-    matmul_n(n, t1, zb, false, t2);       // Z(a) P Z(b)
-    matmul_n(n, t2, P, true, t1);         // Z(a) P Z(b) P^T
-    matmul_n(n, t1, zc, false, t2);       // ... Z(c)
-    float* d = out + kViewD + wigner_block(l);
-    for (int i = 0; i < n * n; ++i) d[i] = (float)t2[i];
-  }
+  for (int j = 1; j < l; ++j) off += (2 * j + 1) * (2 * j + 1);
+  const double* P = conj + off;
+  double* A = buf[l - 1][0];
+  double* B = buf[l - 1][1];
+  // entry (i, j) of X Z(t) for a matrix X: column j mixes columns j and 2l - j
+  auto times_z = [&](const double* X, int i, int j, double t) {
+    const int m = j - l;                                 // Z[j][j] = cos |m| t
+    if (m == 0) return X[i * n + j];
+    const double c = cos(m * t), s_ = sin(m * t);        // Z[2l-j][j] = sin(m t) (sign of m)
+    return X[i * n + j] * c + X[i * n + (2 * l - j)] * s_;
+  };
+  if (on) for (int idx = lane; idx < nn; idx += 64) A[idx] = times_z(P, idx / n, idx % n, ang[1]);
+  __syncthreads();
+  if (on)
+    for (int idx = lane; idx < nn; idx += 64) {          // B = (P Z(b)) P^T
+      const int i = idx / n, j = idx % n;
+      double acc = 0.0;
+      for (int kk = 0; kk < n; ++kk) acc += A[i * n + kk] * P[j * n + kk];
+      B[idx] = acc;
+    }
+  __syncthreads();
+  if (on) for (int idx = lane; idx < nn; idx += 64) A[idx] = times_z(B, idx / n, idx % n, ang[2]);
+  __syncthreads();
+  if (on)
+    for (int idx = lane; idx < nn; idx += 64) {          // rows: Z(a) A
+      const int i = idx / n, j = idx % n, m = l - i;     // Z[i][i] = cos |m| a, Z[i][2l-i] = sin(m a)
+      double val = A[idx];
+      if (m != 0) val = A[idx] * cos(m * ang[0]) + A[(2 * l - i) * n + j] * sin(m * ang[0]);
+      out[kViewD + wigner_block(l) + idx] = (float)val;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -195,16 +201,16 @@ adapter_forward_kernel(AdapterDims dm, float smin, float smax, float eps,
                        float* __restrict__ harmonics) {
   constexpr int K = (DEG + 1) * (DEG + 1), K3 = 3 * K, CIN = 7 + K3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* rawS = lds;                                   // [64][CIN]
-  float* geoS = lds + kWave * CIN;                     // [64 * spp][12]: cov 9 + mean 3
+  float* rawS = lds;                                   // [kEntries][CIN]
+  float* geoS = lds + kEntries * CIN;                  // [kEntries * spp][12]: cov 9 + mean 3
   const int lane = threadIdx.x;
   const int view = blockIdx.y;
-  const int p0 = blockIdx.x * kWave;
-  const int rows = min(kWave, dm.rp - p0);             // entries of this wave
+  const int p0 = blockIdx.x * kEntries;
+  const int rows = min(kEntries, dm.rp - p0);             // entries of this wave
   const size_t e0 = (size_t)view * dm.rp + p0;         // first (view, pixel, surface) entry
   const float* vw = views + (size_t)view * kViewStride;
 
-  stage_slab<(kWave * CIN + 255) / 256>(raw + e0 * CIN, rawS, rows * CIN, lane);
+  stage_slab<(kEntries * CIN + 255) / 256>(raw + e0 * CIN, rawS, rows * CIN, lane);
   wave_lds_sync();
 
   if (lane < rows) {
@@ -284,27 +290,59 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
                         float* __restrict__ d_depths, float* __restrict__ d_coords) {
   constexpr int K = (DEG + 1) * (DEG + 1), K3 = 3 * K, CIN = 7 + K3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* outS = lds;                                   // [64][CIN]: d_raw staging
-  float* geoS = lds + kWave * CIN;                     // [64 * spp][12]: d_cov 9 + d_mean 3
+  float* outS = lds;                                   // [kEntries][CIN]: d_raw staging
+  float* geoS = lds + kEntries * CIN;                  // [kEntries * spp][12]: d_cov 9 + d_mean 3
   const int lane = threadIdx.x;
   const int view = blockIdx.y;
-  const int p0 = blockIdx.x * kWave;
-  const int rows = min(kWave, dm.rp - p0);
+  const int p0 = blockIdx.x * kEntries;
+  const int rows = min(kEntries, dm.rp - p0);
   const size_t e0 = (size_t)view * dm.rp + p0;
   const float* vw = views + (size_t)view * kViewStride;
   const size_t g0 = e0 * dm.spp;
   const int n_g = rows * dm.spp;
 
-  // incoming gradients: coalesced into LDS; the harmonics of the spp samples are summed on
-  // the way in (they share one raw vector)
-  for (int i = lane; i < n_g * 9; i += kWave) geoS[(i / 9) * 12 + i % 9] = d_cov[g0 * 9 + i];
-  for (int i = lane; i < n_g * 3; i += kWave) geoS[(i / 3) * 12 + 9 + i % 3] = d_means[g0 * 3 + i];
-  const float* hin = d_harmonics + g0 * K3;
-  for_each_row_element(rows, K3, lane, [&](int r, int j) {
-    float acc = 0.f;
-    for (int k = 0; k < dm.spp; ++k) acc += hin[((size_t)r * dm.spp + k) * K3 + j];
-    outS[r * CIN + 7 + j] = acc;
-  });
+  // incoming gradients: coalesced into LDS, eight loads in flight per lane (a load -> LDS store
+  // per iteration is a chain of memory latencies: 100 us per wave in the first version); the
+  // harmonics of the spp samples are summed on the way in (they share one raw vector)
+  {
+    constexpr int U = 8;
+    for (int i0 = lane; i0 < n_g * 9; i0 += kWave * U) {
+      float r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = i0 + u * kWave; r[u] = i < n_g * 9 ? d_cov[g0 * 9 + i] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = i0 + u * kWave; if (i < n_g * 9) geoS[(i / 9) * 12 + i % 9] = r[u]; }
+    }
+    for (int i0 = lane; i0 < n_g * 3; i0 += kWave * U) {
+      float r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = i0 + u * kWave; r[u] = i < n_g * 3 ? d_means[g0 * 3 + i] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = i0 + u * kWave; if (i < n_g * 3) geoS[(i / 3) * 12 + 9 + i % 3] = r[u]; }
+    }
+    // all rows x samples of the wave are one contiguous [n_g][K3] block: walk it linearly,
+    // element o belongs to entry o / (spp K3), coefficient o % K3
+    const float* hin = d_harmonics + g0 * K3;
+    const int total = n_g * K3, per_entry = dm.spp * K3;
+    for (int i = lane; i < rows * CIN; i += kWave) outS[i] = 0.f;
+    wave_lds_sync();
+    for (int o0 = lane; o0 < total; o0 += kWave * U) {
+      float r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int o = o0 + u * kWave; r[u] = o < total ? hin[o] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int o = o0 + u * kWave;
+        if (o < total) {
+          const int ent = o / per_entry, j = (o - ent * per_entry) % K3;
+          // lanes of one instruction hit distinct (entry, j) unless spp rows of an entry fall
+          // into the same 64-element window (K3 >= 64: they never do; else serialise)
+          if (K3 >= kWave) outS[ent * CIN + 7 + j] += r[u];
+          else atomicAdd(&outS[ent * CIN + 7 + j], r[u]);
+        }
+      }
+    }
+  }
   wave_lds_sync();
 
   if (lane < rows) {
@@ -432,14 +470,14 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
 int launch_adapter_views(int n_views, int sh_degree, int img_h, int img_w, const float* extrinsics,
                          const float* intrinsics, const double* conj, float* views,
                          hipStream_t st) {
-  hipLaunchKernelGGL(adapter_view_kernel, dim3((n_views + 63) / 64), dim3(64), 0, st, n_views,
+  hipLaunchKernelGGL(adapter_view_kernel, dim3(n_views), dim3(256), 0, st, n_views,
                      sh_degree, img_h, img_w, extrinsics, intrinsics, conj, views);
   return PS_OK;
 }
 
 static size_t adapter_lds(int deg, int spp) {
   const int cin = 7 + 3 * (deg + 1) * (deg + 1);
-  return (size_t)kWave * (cin + 12 * spp) * sizeof(float);
+  return (size_t)kEntries * (cin + 12 * spp) * sizeof(float);
 }
 
 int launch_adapter_forward(int n_views, int rp, int spp, int sh_degree, float smin, float smax,
@@ -449,7 +487,7 @@ int launch_adapter_forward(int n_views, int rp, int spp, int sh_degree, float sm
   if (sh_degree < 0 || sh_degree > 4 || spp < 1 || adapter_lds(sh_degree, spp) > 160 * 1024)
     return PS_ERR_UNSUPPORTED;
   const AdapterDims dm{n_views, rp, spp, (sh_degree + 1) * (sh_degree + 1)};
-  dim3 grid((rp + kWave - 1) / kWave, n_views), block(kWave);
+  dim3 grid((rp + kEntries - 1) / kEntries, n_views), block(kWave);
   const size_t sm = adapter_lds(sh_degree, spp);
 #define PS_GO(D)                                                                              \
   do {                                                                                        \
@@ -474,7 +512,7 @@ int launch_adapter_backward(int n_views, int rp, int spp, int sh_degree, float s
   if (sh_degree < 0 || sh_degree > 4 || spp < 1 || adapter_lds(sh_degree, spp) > 160 * 1024)
     return PS_ERR_UNSUPPORTED;
   const AdapterDims dm{n_views, rp, spp, (sh_degree + 1) * (sh_degree + 1)};
-  dim3 grid((rp + kWave - 1) / kWave, n_views), block(kWave);
+  dim3 grid((rp + kEntries - 1) / kEntries, n_views), block(kWave);
   const size_t sm = adapter_lds(sh_degree, spp);
 #define PS_GO(D)                                                                              \
   do {                                                                                        \
