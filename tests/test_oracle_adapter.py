@@ -63,3 +63,33 @@ def test_rotate_sh_degree_one_rotates_vectors():
     out = A.rotate_sh(sh, r)
     assert torch.allclose(out[:, 0], sh[:, 0])
     assert torch.allclose(out[:, 1:4], torch.einsum("nij,nj->ni", r, sh[:, 1:4]), atol=1e-12)
+
+
+def test_product_wigner_constants_against_oracle_generators():
+    """Host logic of the product (pixelsplat_amd/wigner.py): the closed form
+    D = Z(a) P Z(b) P^T Z(c) evaluated with its constants equals the oracle's
+    exp(a G_y) exp(b G_x) exp(c G_y)."""
+    from pixelsplat_amd import wigner as W
+
+    p = W.conjugation_matrices()
+    assert p.shape == (164,)
+
+    def z(l, t):
+        n = 2 * l + 1
+        m = np.zeros((n, n))
+        m[l, l] = 1
+        for k in range(1, l + 1):
+            m[l - k, l - k] = m[l + k, l + k] = np.cos(k * t)
+            m[l - k, l + k] = np.sin(k * t)
+            m[l + k, l - k] = -np.sin(k * t)
+        return m
+
+    a, b, c = 0.7, -1.9, 2.4
+    off = 0
+    for l in range(1, 5):
+        n = 2 * l + 1
+        pl = p[off:off + n * n].reshape(n, n)
+        off += n * n
+        d = z(l, a) @ pl @ z(l, b) @ pl.T @ z(l, c)
+        ref = A.wigner_D(l, *(torch.tensor(x, dtype=torch.float64) for x in (a, b, c))).numpy()
+        assert np.abs(d - ref).max() < 1e-12
