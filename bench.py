@@ -248,6 +248,20 @@ def main():
                 ga_in["raw"], hw)
         (g_.means.sum() + g_.covariances.sum() + g_.harmonics.sum()).backward()
 
+    # ---- depth predictor: ReLU + Linear + the fused sampler, same rays
+    from pixelsplat_amd.encoder import DepthPredictorMonocular
+    dp = DepthPredictorMonocular(d_feat, 32, 1, False).to(dev)
+    dp_feat = torch.randn(b, 2, n_rays, d_feat, device=dev).requires_grad_(True)
+    dp_near = torch.full((b, 2), 1.0, device=dev)
+    dp_far = torch.full((b, 2), 100.0, device=dev)
+
+    def step_depth():
+        dp_feat.grad = None
+        for p_ in dp.parameters():
+            p_.grad = None
+        dep, opa = dp.forward_mapped(dp_feat, dp_near, dp_far, False, 3, 1.0, 1.0 / 3)
+        (dep.sum() + opa.sum()).backward()
+
     def timed(fn, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -286,7 +300,17 @@ def main():
     ms_b = timed(lambda: step(a=False), args.steps)
     ms_a = timed(lambda: step(b_=False), args.steps)
     step_adapter()
+    step_depth()
+    lib.ps_profile_enable(1)
     ms_ga = timed(step_adapter, args.steps)
+    ms_dp = timed(step_depth, args.steps)
+    lib.ps_profile_enable(0)
+    side_ms = (C.c_double * ng)()
+    side_n = (C.c_int64 * ng)()
+    _lib.check(lib.ps_profile_collect(side_ms, side_n), "ps_profile_collect")
+    for i in range(ng):   # the groups only these two probes launch
+        if launches[i] == 0 and side_n[i]:
+            tot_ms[i], launches[i] = side_ms[i], side_n[i]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -353,6 +377,9 @@ def main():
                 # next row of SURVEY.md 8(f): raw network outputs -> Gaussians, fwd + bwd incl.
                 # the three torch .sum() reductions of this probe; not part of `value`
                 "gaussian_adapter_only_ms_per_step": round(ms_ga, 3),
+                # rank 3: features -> (depth, opacity): ReLU + Linear (library GEMM, split-k
+                # weight gradient) + ps_depth_sampler_*, fwd + bwd; not part of `value`
+                "depth_predictor_only_ms_per_step": round(ms_dp, 3),
                 "epipolar_reference_equivalent_tflops": round(
                     3.0 * 2 * (2.0 * RA * (2 * d_feat * 512 + TA * d_feat * 1024 + 2 * 4 * TA * 128))
                     / (ms_a * 1e-3) / 1e12, 1),

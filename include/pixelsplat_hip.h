@@ -284,6 +284,36 @@ int ps_gaussian_adapter_backward(int32_t n_views, int32_t entries_per_view, int3
                                  float* d_raw, float* d_depths, float* d_coordinates,
                                  void* stream);
 
+/* ---- Depth predictor sampling ------------------------------------------
+ * Replaces everything DepthPredictorMonocular.forward does after its linear projection
+ * (src/model/encoder/epipolar/depth_predictor_monocular.py:52-81): the "(dpt srf c)" split,
+ * softmax / sigmoid, DistributionSampler.sample + gather
+ * (src/misc/discrete_probability_distribution.py:7-33, epipolar/distribution_sampler.py:11-51),
+ * relative_disparity_to_depth (epipolar/conversions.py:5-14), the optional transmittance
+ * opacity, and -- when opacity_exponent != 0 -- the encoder's map_pdf_to_opacity and 1/gpp
+ * (encoder_epipolar.py:97-110, :170).  Rows = (view, ray, surface).
+ *   projected  float[n_views][rays][2 * buckets * surfaces]   output of the nn.Linear
+ *   near, far  float[n_views]
+ *   uniforms   float[n_views][rays][surfaces][spp]  the torch.rand draw of the sampler;
+ *              NULL iff deterministic (then sample t is the t-th most probable bucket)
+ *   depth, opacity float[rows][spp];  index int32[rows][spp] (kept for the backward)
+ * A ray's buckets * surfaces logits (x2 for the backward, x4 with transmittance) must fit the
+ * 9 KB per-wave LDS slab -- buckets * surfaces <= 512 always does -- else PS_ERR_UNSUPPORTED. */
+typedef struct PsDepthSamplerDesc {
+  int32_t n_views, rays_per_view, buckets, surfaces, spp;
+  int32_t deterministic;      /* 1: gather_discrete_topk, 0: sample_discrete_distribution */
+  int32_t use_transmittance;  /* depth_predictor_monocular.py:71-78 */
+  float opacity_exponent;     /* 2**x of encoder_epipolar.py:106-107; 0 = return the density */
+  float opacity_scale;        /* 1/gaussians_per_pixel of :170; 1 for the bare module */
+} PsDepthSamplerDesc;
+int ps_depth_sampler_forward(const PsDepthSamplerDesc* desc, const float* projected,
+                             const float* near, const float* far, const float* uniforms,
+                             float* depth, float* opacity, int32_t* index, void* stream);
+int ps_depth_sampler_backward(const PsDepthSamplerDesc* desc, const float* projected,
+                              const float* near, const float* far, const int32_t* index,
+                              const float* d_depth, const float* d_opacity, float* d_projected,
+                              void* stream);
+
 /* Feature-map gradient of n_layers (1 or 2) attention layers that share the geometry, in ONE
  * scatter pass: dfmap = sum over layers of the gradient ps_epipolar_attention_backward would
  * write for that layer (call that function with dfmap = NULL and hand its ds here).  qt, attn,

@@ -42,6 +42,12 @@ class PsEpipolarDesc(C.Structure):
                                          "hs_in", "hs_out")]
 
 
+class PsDepthSamplerDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_views", "rays_per_view", "buckets", "surfaces", "spp",
+                                         "deterministic", "use_transmittance")] + [
+        ("opacity_exponent", C.c_float), ("opacity_scale", C.c_float)]
+
+
 # every symbol include/pixelsplat_hip.h declares
 EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
@@ -52,6 +58,7 @@ EXPORTS = [
     "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
     "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_gaussian_adapter_views",
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
+    "ps_depth_sampler_forward", "ps_depth_sampler_backward",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
 ]
 
@@ -122,6 +129,11 @@ def load():
     lib.ps_gaussian_adapter_forward.restype = C.c_int
     lib.ps_gaussian_adapter_backward.argtypes = [C.c_int32] * 4 + [C.c_float] * 3 + [vp] * 11
     lib.ps_gaussian_adapter_backward.restype = C.c_int
+    pd = C.POINTER(PsDepthSamplerDesc)
+    lib.ps_depth_sampler_forward.argtypes = [pd] + [vp] * 8
+    lib.ps_depth_sampler_forward.restype = C.c_int
+    lib.ps_depth_sampler_backward.argtypes = [pd] + [vp] * 8
+    lib.ps_depth_sampler_backward.restype = C.c_int
     lib.ps_invert_cameras.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
     lib.ps_invert_cameras.restype = C.c_int
     lib.ps_gemm_tn_workspace_bytes.argtypes = [C.c_int32] * 3

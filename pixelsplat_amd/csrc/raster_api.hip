@@ -13,13 +13,14 @@ namespace {
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
 enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET,
              G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_GEMM_TN, G_ADAPTER_FWD, G_ADAPTER_BWD,
-             G_COUNT };
+             G_DEPTH_FWD, G_DEPTH_BWD, G_COUNT };
 const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
                                     "tiles_backward", "preprocess_backward", "memset",
                                     "epipolar_geometry", "epipolar_attention_forward",
                                     "epipolar_attention_backward", "epipolar_feature_grad",
                                     "gemm_tn_splitk", "gaussian_adapter_forward",
-                                    "gaussian_adapter_backward"};
+                                    "gaussian_adapter_backward", "depth_sampler_forward",
+                                    "depth_sampler_backward"};
 std::atomic<int> g_profile_on{0};
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
@@ -384,6 +385,41 @@ int ps_gaussian_adapter_backward(int32_t n_views, int32_t entries_per_view, int3
                                        scale_max, eps, views, coordinates, depths, raw, d_means,
                                        d_covariances, d_harmonics, d_raw, d_depths, d_coordinates,
                                        (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+namespace {
+bool depth_desc_ok(const PsDepthSamplerDesc* d) {
+  return d && d->n_views > 0 && d->rays_per_view > 0 && d->buckets > 0 && d->surfaces > 0 &&
+         d->spp > 0 && (!d->deterministic || d->spp <= d->buckets) &&
+         (long long)d->n_views * d->rays_per_view * d->surfaces < (1ll << 31) - 4096;
+}
+}  // namespace
+
+int ps_depth_sampler_forward(const PsDepthSamplerDesc* desc, const float* projected,
+                             const float* near, const float* far, const float* uniforms,
+                             float* depth, float* opacity, int32_t* index, void* stream) {
+  if (!depth_desc_ok(desc) || !projected || !near || !far || !depth || !opacity || !index ||
+      (!desc->deterministic && !uniforms))
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_DEPTH_FWD, (hipStream_t)stream);
+  if (int rc = launch_depth_sampler_forward(*desc, projected, near, far, uniforms, depth, opacity,
+                                            index, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_depth_sampler_backward(const PsDepthSamplerDesc* desc, const float* projected,
+                              const float* near, const float* far, const int32_t* index,
+                              const float* d_depth, const float* d_opacity, float* d_projected,
+                              void* stream) {
+  if (!depth_desc_ok(desc) || !projected || !near || !far || !index || !d_depth || !d_opacity ||
+      !d_projected)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_DEPTH_BWD, (hipStream_t)stream);
+  if (int rc = launch_depth_sampler_backward(*desc, projected, near, far, index, d_depth,
+                                             d_opacity, d_projected, (hipStream_t)stream))
     return rc;
   return check_launch();
 }

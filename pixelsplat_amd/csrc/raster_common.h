@@ -179,6 +179,13 @@ int launch_adapter_backward(int n_views, int rp, int spp, int sh_degree, float s
                             const float* depths, const float* raw, const float* d_means,
                             const float* d_cov, const float* d_harmonics, float* d_raw,
                             float* d_depths, float* d_coords, hipStream_t st);
+int launch_depth_sampler_forward(const PsDepthSamplerDesc& d, const float* projected,
+                                 const float* near, const float* far, const float* uniforms,
+                                 float* depth, float* opacity, int32_t* index, hipStream_t st);
+int launch_depth_sampler_backward(const PsDepthSamplerDesc& d, const float* projected,
+                                  const float* near, const float* far, const int32_t* index,
+                                  const float* d_depth, const float* d_opacity,
+                                  float* d_projected, hipStream_t st);
 void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
                            hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);

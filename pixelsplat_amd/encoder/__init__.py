@@ -2,6 +2,7 @@
 constructor arguments, parameter / buffer names (released checkpoints load unchanged) and
 return types; the sampler geometry, feature gather and cross-attention run on the HIP
 kernels of libpixelsplat_hip.so."""
+from .depth_predictor import DepthPredictorMonocular, sample_depths  # noqa: F401
 from .epipolar_sampler import EpipolarSampler, EpipolarSampling  # noqa: F401
 from .epipolar_transformer import (EpipolarTransformer, EpipolarTransformerCfg,  # noqa: F401
                                    ImageSelfAttentionCfg)
