@@ -166,6 +166,7 @@ def main():
 
     from pixelsplat_amd import _lib
     from pixelsplat_amd.decoder import render_cuda
+    from pixelsplat_amd.loss import mse_and_psnr
     from pixelsplat_amd.raster import export_bins
     from pixelsplat_amd.synthetic import make_workload
 
@@ -218,7 +219,7 @@ def main():
 
     def path_b():
         img = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v)
-        return ((img - tgt_img) ** 2).mean()
+        return mse_and_psnr(img, tgt_img, 1.0)[0]   # LossMse (loss_mse.py:30-31), one pass
 
     def zero_grads():
         for t in (means, cov, sh, op, feat, *a_params):

@@ -314,6 +314,37 @@ int ps_depth_sampler_backward(const PsDepthSamplerDesc* desc, const float* proje
                               const float* d_depth, const float* d_opacity, float* d_projected,
                               void* stream);
 
+/* ---- Image-side losses -------------------------------------------------
+ * ps_image_mse: LossMse (src/loss/loss_mse.py:22-31) and compute_psnr
+ * (src/evaluation/metrics.py:12-19) in one pass over n_images images of `elems` floats each
+ * (c*h*w): sse[i] = sum (pred - target)^2, sse_clipped[i] = the same on values clipped to
+ * [0, 1] (may be NULL), grad = grad_scale * (pred - target) (may be NULL) -- with
+ * grad_scale = 2 * weight / (n_images * elems) that is dLoss/dpred, the dL_dimage of
+ * ps_raster_backward.  loss = weight * sum(sse) / (n_images * elems);
+ * psnr[i] = -10 log10(sse_clipped[i] / elems).  Deterministic (fixed-order partial sums). */
+size_t ps_image_mse_workspace_bytes(int32_t n_images, int32_t elems);
+int ps_image_mse(int32_t n_images, int32_t elems, const float* pred, const float* target,
+                 float grad_scale, float* grad, float* sse, float* sse_clipped, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* LossDepth (src/loss/loss_depth.py:26-60): depth [n_images][h][w] clamped to
+ * [log near, log far] and normalised, first (or second) differences along x and y, optional
+ * bilateral weights exp(-sigma * max_c diff(target)), weight * (mean|dx| + mean|dy|).
+ * loss: device float[1].  backward: d_depth = d_loss[0] * dLoss/ddepth (d_loss: device float[1]). */
+typedef struct PsDepthLossDesc {
+  int32_t n_images, height, width, channels;
+  int32_t use_second_derivative;
+  int32_t use_sigma;       /* 0: sigma_image is None (target_image may be NULL) */
+  float sigma_image, weight;
+} PsDepthLossDesc;
+size_t ps_depth_smoothness_workspace_bytes(const PsDepthLossDesc* desc);
+int ps_depth_smoothness_forward(const PsDepthLossDesc* desc, const float* depth, const float* near,
+                                const float* far, const float* target_image, float* loss,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int ps_depth_smoothness_backward(const PsDepthLossDesc* desc, const float* depth,
+                                 const float* near, const float* far, const float* target_image,
+                                 const float* d_loss, float* d_depth, void* stream);
+
 /* Feature-map gradient of n_layers (1 or 2) attention layers that share the geometry, in ONE
  * scatter pass: dfmap = sum over layers of the gradient ps_epipolar_attention_backward would
  * write for that layer (call that function with dfmap = NULL and hand its ds here).  qt, attn,

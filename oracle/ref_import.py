@@ -75,3 +75,30 @@ def adapter_modules() -> SimpleNamespace:
         sh_rotation=imp("src.misc.sh_rotation"),
         projection=imp("src.geometry.projection"),
     )
+
+
+def loss_modules() -> SimpleNamespace:
+    """The reference's LossMse / LossDepth / compute_psnr.  Their modules import the dataset
+    package (for a type annotation) and lpips / skimage (for the other metrics in the same
+    file); those get attribute-only stand-ins, the loss code itself is the reference's."""
+    setup(2)
+    for name in ("src.loss", "src.evaluation", "src.dataset"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF, *name.split("."))]
+            sys.modules[name] = m
+    sys.modules["src.dataset"].DatasetCfg = object
+    for name, attrs in (("lpips", ("LPIPS",)), ("skimage", ()),
+                        ("skimage.metrics", ("structural_similarity",))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, object)
+            sys.modules[name] = m
+    imp = importlib.import_module
+    return SimpleNamespace(
+        mse=imp("src.loss.loss_mse"),
+        depth=imp("src.loss.loss_depth"),
+        metrics=imp("src.evaluation.metrics"),
+        decoder=imp("src.model.decoder.decoder"),
+    )

@@ -48,6 +48,12 @@ class PsDepthSamplerDesc(C.Structure):
         ("opacity_exponent", C.c_float), ("opacity_scale", C.c_float)]
 
 
+class PsDepthLossDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_images", "height", "width", "channels",
+                                         "use_second_derivative", "use_sigma")] + [
+        ("sigma_image", C.c_float), ("weight", C.c_float)]
+
+
 # every symbol include/pixelsplat_hip.h declares
 EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
@@ -59,6 +65,8 @@ EXPORTS = [
     "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_gaussian_adapter_views",
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
     "ps_depth_sampler_forward", "ps_depth_sampler_backward",
+    "ps_image_mse_workspace_bytes", "ps_image_mse", "ps_depth_smoothness_workspace_bytes",
+    "ps_depth_smoothness_forward", "ps_depth_smoothness_backward",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
 ]
 
@@ -134,6 +142,18 @@ def load():
     lib.ps_depth_sampler_forward.restype = C.c_int
     lib.ps_depth_sampler_backward.argtypes = [pd] + [vp] * 8
     lib.ps_depth_sampler_backward.restype = C.c_int
+    lib.ps_image_mse_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.ps_image_mse_workspace_bytes.restype = C.c_size_t
+    lib.ps_image_mse.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_float, vp, vp, vp, vp,
+                                 C.c_size_t, vp]
+    lib.ps_image_mse.restype = C.c_int
+    pl = C.POINTER(PsDepthLossDesc)
+    lib.ps_depth_smoothness_workspace_bytes.argtypes = [pl]
+    lib.ps_depth_smoothness_workspace_bytes.restype = C.c_size_t
+    lib.ps_depth_smoothness_forward.argtypes = [pl, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.ps_depth_smoothness_forward.restype = C.c_int
+    lib.ps_depth_smoothness_backward.argtypes = [pl] + [vp] * 7
+    lib.ps_depth_smoothness_backward.restype = C.c_int
     lib.ps_invert_cameras.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
     lib.ps_invert_cameras.restype = C.c_int
     lib.ps_gemm_tn_workspace_bytes.argtypes = [C.c_int32] * 3

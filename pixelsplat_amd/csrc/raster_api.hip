@@ -13,14 +13,14 @@ namespace {
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
 enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET,
              G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_GEMM_TN, G_ADAPTER_FWD, G_ADAPTER_BWD,
-             G_DEPTH_FWD, G_DEPTH_BWD, G_COUNT };
+             G_DEPTH_FWD, G_DEPTH_BWD, G_LOSS, G_COUNT };
 const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
                                     "tiles_backward", "preprocess_backward", "memset",
                                     "epipolar_geometry", "epipolar_attention_forward",
                                     "epipolar_attention_backward", "epipolar_feature_grad",
                                     "gemm_tn_splitk", "gaussian_adapter_forward",
                                     "gaussian_adapter_backward", "depth_sampler_forward",
-                                    "depth_sampler_backward"};
+                                    "depth_sampler_backward", "image_losses"};
 std::atomic<int> g_profile_on{0};
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
@@ -420,6 +420,63 @@ int ps_depth_sampler_backward(const PsDepthSamplerDesc* desc, const float* proje
   Scope sc(G_DEPTH_BWD, (hipStream_t)stream);
   if (int rc = launch_depth_sampler_backward(*desc, projected, near, far, index, d_depth,
                                              d_opacity, d_projected, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+size_t ps_image_mse_workspace_bytes(int32_t n_images, int32_t elems) {
+  if (n_images <= 0 || elems <= 0) return 0;
+  return image_mse_workspace_bytes(n_images, elems);
+}
+
+int ps_image_mse(int32_t n_images, int32_t elems, const float* pred, const float* target,
+                 float grad_scale, float* grad, float* sse, float* sse_clipped, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  if (n_images <= 0 || elems <= 0 || n_images > 65535 || !pred || !target || !sse || !workspace)
+    return PS_ERR_BAD_ARG;
+  if (workspace_bytes < image_mse_workspace_bytes(n_images, elems)) return PS_ERR_WORKSPACE;
+  Scope sc(G_LOSS, (hipStream_t)stream);
+  if (int rc = launch_image_mse(n_images, elems, pred, target, grad_scale, grad, sse, sse_clipped,
+                                workspace, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+namespace {
+bool depth_loss_desc_ok(const PsDepthLossDesc* d) {
+  if (!d || d->n_images <= 0 || d->n_images > 65535 || d->channels < 0) return false;
+  const int o = d->use_second_derivative ? 2 : 1;
+  return d->height > o && d->width > o && (long long)d->height * d->width < (1ll << 31);
+}
+}  // namespace
+
+size_t ps_depth_smoothness_workspace_bytes(const PsDepthLossDesc* desc) {
+  return depth_loss_desc_ok(desc) ? depth_smoothness_workspace_bytes(*desc) : 0;
+}
+
+int ps_depth_smoothness_forward(const PsDepthLossDesc* desc, const float* depth, const float* near,
+                                const float* far, const float* target_image, float* loss,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!depth_loss_desc_ok(desc) || !depth || !near || !far || !loss || !workspace ||
+      (desc->use_sigma && (!target_image || desc->channels <= 0)))
+    return PS_ERR_BAD_ARG;
+  if (workspace_bytes < depth_smoothness_workspace_bytes(*desc)) return PS_ERR_WORKSPACE;
+  Scope sc(G_LOSS, (hipStream_t)stream);
+  if (int rc = launch_depth_smoothness_forward(*desc, depth, near, far, target_image, loss,
+                                               workspace, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_depth_smoothness_backward(const PsDepthLossDesc* desc, const float* depth,
+                                 const float* near, const float* far, const float* target_image,
+                                 const float* d_loss, float* d_depth, void* stream) {
+  if (!depth_loss_desc_ok(desc) || !depth || !near || !far || !d_loss || !d_depth ||
+      (desc->use_sigma && (!target_image || desc->channels <= 0)))
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_LOSS, (hipStream_t)stream);
+  if (int rc = launch_depth_smoothness_backward(*desc, depth, near, far, target_image, d_loss,
+                                                d_depth, (hipStream_t)stream))
     return rc;
   return check_launch();
 }

@@ -186,6 +186,17 @@ int launch_depth_sampler_backward(const PsDepthSamplerDesc& d, const float* proj
                                   const float* near, const float* far, const int32_t* index,
                                   const float* d_depth, const float* d_opacity,
                                   float* d_projected, hipStream_t st);
+size_t image_mse_workspace_bytes(int n_images, int elems);
+int launch_image_mse(int n_images, int elems, const float* pred, const float* target,
+                     float grad_scale, float* grad, float* sse, float* sse_clipped,
+                     void* workspace, hipStream_t st);
+size_t depth_smoothness_workspace_bytes(const PsDepthLossDesc& d);
+int launch_depth_smoothness_forward(const PsDepthLossDesc& d, const float* depth,
+                                    const float* near, const float* far, const float* image,
+                                    float* loss, void* workspace, hipStream_t st);
+int launch_depth_smoothness_backward(const PsDepthLossDesc& d, const float* depth,
+                                     const float* near, const float* far, const float* image,
+                                     const float* d_loss, float* d_depth, hipStream_t st);
 void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
                            hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
