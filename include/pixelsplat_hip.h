@@ -284,6 +284,25 @@ int ps_gaussian_adapter_backward(int32_t n_views, int32_t entries_per_view, int3
                                  float* d_raw, float* d_depths, float* d_coordinates,
                                  void* stream);
 
+/* The same kernels on the encoder head's own layout (encoder_epipolar.py:149-173): head_rows
+ * float[n_views][image_h * image_w][surfaces][2 + 7 + 3 (deg+1)^2] is the output of the
+ * `to_gaussians` linear layer as it stands -- [xy offset (2) | scale (3) | quaternion (4) | SH] --
+ * and the ray of an entry is its pixel centre ((x + .5) / w, (y + .5) / h) of sample_image_grid
+ * (src/geometry/projection.py:111-140) moved by (sigmoid(offset) - 0.5) pixels (:155-164): no
+ * slice copy of the 82 of 84 columns, no coordinate tensor, and d_head_rows is directly the
+ * gradient of the linear layer's output. */
+int ps_gaussian_head_forward(int32_t n_views, int32_t image_h, int32_t image_w, int32_t surfaces,
+                             int32_t spp, int32_t sh_degree, float scale_min, float scale_max,
+                             float eps, const float* views, const float* depths,
+                             const float* head_rows, float* means, float* covariances,
+                             float* harmonics, void* stream);
+int ps_gaussian_head_backward(int32_t n_views, int32_t image_h, int32_t image_w, int32_t surfaces,
+                              int32_t spp, int32_t sh_degree, float scale_min, float scale_max,
+                              float eps, const float* views, const float* depths,
+                              const float* head_rows, const float* d_means,
+                              const float* d_covariances, const float* d_harmonics,
+                              float* d_head_rows, float* d_depths, void* stream);
+
 /* ---- Depth predictor sampling ------------------------------------------
  * Replaces everything DepthPredictorMonocular.forward does after its linear projection
  * (src/model/encoder/epipolar/depth_predictor_monocular.py:52-81): the "(dpt srf c)" split,

@@ -64,6 +64,7 @@ EXPORTS = [
     "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
     "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_gaussian_adapter_views",
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
+    "ps_gaussian_head_forward", "ps_gaussian_head_backward",
     "ps_depth_sampler_forward", "ps_depth_sampler_backward",
     "ps_image_mse_workspace_bytes", "ps_image_mse", "ps_depth_smoothness_workspace_bytes",
     "ps_depth_smoothness_forward", "ps_depth_smoothness_backward",
@@ -137,6 +138,10 @@ def load():
     lib.ps_gaussian_adapter_forward.restype = C.c_int
     lib.ps_gaussian_adapter_backward.argtypes = [C.c_int32] * 4 + [C.c_float] * 3 + [vp] * 11
     lib.ps_gaussian_adapter_backward.restype = C.c_int
+    lib.ps_gaussian_head_forward.argtypes = [C.c_int32] * 6 + [C.c_float] * 3 + [vp] * 7
+    lib.ps_gaussian_head_forward.restype = C.c_int
+    lib.ps_gaussian_head_backward.argtypes = [C.c_int32] * 6 + [C.c_float] * 3 + [vp] * 9
+    lib.ps_gaussian_head_backward.restype = C.c_int
     pd = C.POINTER(PsDepthSamplerDesc)
     lib.ps_depth_sampler_forward.argtypes = [pd] + [vp] * 8
     lib.ps_depth_sampler_forward.restype = C.c_int

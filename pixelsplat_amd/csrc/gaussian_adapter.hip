@@ -114,7 +114,24 @@ adapter_view_kernel(int n_views, int sh_degree, int img_h, int img_w,
 // ---------------------------------------------------------------------------------------
 // shared per-lane math
 // ---------------------------------------------------------------------------------------
-struct AdapterDims { int n_views, rp /* pixels * surfaces per view */, spp, k /* SH per channel */; };
+struct AdapterDims {
+  int n_views, rp /* pixels * surfaces per view */, spp, k /* SH per channel */;
+  int srf, grid_w, grid_h;   // head layout only: surfaces per pixel and the pixel grid
+};
+
+// Head layout (SKIP = 2): an entry row is the whole output row of the encoder's `to_gaussians`
+// linear layer for one (pixel, surface) -- [xy offset (2) | scale (3) | quaternion (4) | SH] --
+// and the ray coordinate is the pixel centre moved by (sigmoid(offset) - 0.5) pixels
+// (encoder_epipolar.py:155-164): no slice copy, no coordinate tensor.
+__device__ __forceinline__ float2 head_coordinates(const AdapterDims& dm, int entry, float ox,
+                                                   float oy, float* sig_out) {
+  const int ray = entry / dm.srf, y = ray / dm.grid_w, x = ray - y * dm.grid_w;
+  const float sx = 1.f / (1.f + expf(-ox)), sy = 1.f / (1.f + expf(-oy));
+  sig_out[0] = sx; sig_out[1] = sy;
+  const float pw = 1.f / (float)dm.grid_w, ph = 1.f / (float)dm.grid_h;
+  return make_float2(((float)x + 0.5f) / (float)dm.grid_w + (sx - 0.5f) * pw,
+                     ((float)y + 0.5f) / (float)dm.grid_h + (sy - 0.5f) * ph);
+}
 
 struct LaneGeom {
   float base[3];      // scale before depth * multiplier
@@ -192,14 +209,14 @@ __device__ __forceinline__ void for_each_row_element(int rows, int k3, int lane,
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, int SKIP>
 __global__ void __launch_bounds__(kWave)
 adapter_forward_kernel(AdapterDims dm, float smin, float smax, float eps,
                        const float* __restrict__ views, const float* __restrict__ coords,
                        const float* __restrict__ depths, const float* __restrict__ raw,
                        float* __restrict__ means, float* __restrict__ cov,
                        float* __restrict__ harmonics) {
-  constexpr int K = (DEG + 1) * (DEG + 1), K3 = 3 * K, CIN = 7 + K3;
+  constexpr int K = (DEG + 1) * (DEG + 1), K3 = 3 * K, CIN = SKIP + 7 + K3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* rawS = lds;                                   // [kEntries][CIN]
   float* geoS = lds + kEntries * CIN;                  // [kEntries * spp][12]: cov 9 + mean 3
@@ -214,11 +231,17 @@ adapter_forward_kernel(AdapterDims dm, float smin, float smax, float eps,
   wave_lds_sync();
 
   if (lane < rows) {
-    float* mine = rawS + lane * CIN;
+    float* mine = rawS + lane * CIN + SKIP;
     float raw7[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) raw7[i] = mine[i];
-    const float2 cxy = *reinterpret_cast<const float2*>(coords + 2 * (e0 + lane));
+    float2 cxy;
+    if (SKIP) {
+      float sig_xy[2];
+      cxy = head_coordinates(dm, p0 + lane, mine[-2], mine[-1], sig_xy);
+    } else {
+      cxy = *reinterpret_cast<const float2*>(coords + 2 * (e0 + lane));
+    }
     LaneGeom g;
     lane_geometry(vw, raw7, cxy.x, cxy.y, smin, smax, eps, g);
     const float mult = vw[kViewMult];
@@ -273,14 +296,14 @@ adapter_forward_kernel(AdapterDims dm, float smin, float smax, float eps,
   for (int i = lane; i < n_g * 3; i += kWave) means[g0 * 3 + i] = geoS[(i / 3) * 12 + 9 + i % 3];
   float* hout = harmonics + g0 * K3;
   for_each_row_element(n_g, K3, lane, [&](int r, int j) {
-    hout[(size_t)r * K3 + j] = rawS[(r / dm.spp) * CIN + 7 + j];
+    hout[(size_t)r * K3 + j] = rawS[(r / dm.spp) * CIN + SKIP + 7 + j];
   });
 }
 
 // ---------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, int SKIP>
 __global__ void __launch_bounds__(kWave)
 adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
                         const float* __restrict__ views, const float* __restrict__ coords,
@@ -288,7 +311,7 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
                         const float* __restrict__ d_means, const float* __restrict__ d_cov,
                         const float* __restrict__ d_harmonics, float* __restrict__ d_raw,
                         float* __restrict__ d_depths, float* __restrict__ d_coords) {
-  constexpr int K = (DEG + 1) * (DEG + 1), K3 = 3 * K, CIN = 7 + K3;
+  constexpr int K = (DEG + 1) * (DEG + 1), K3 = 3 * K, CIN = SKIP + 7 + K3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* outS = lds;                                   // [kEntries][CIN]: d_raw staging
   float* geoS = lds + kEntries * CIN;                  // [kEntries * spp][12]: d_cov 9 + d_mean 3
@@ -337,8 +360,8 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
           const int ent = o / per_entry, j = (o - ent * per_entry) % K3;
           // lanes of one instruction hit distinct (entry, j) unless spp rows of an entry fall
           // into the same 64-element window (K3 >= 64: they never do; else serialise)
-          if (K3 >= kWave) outS[ent * CIN + 7 + j] += r[u];
-          else atomicAdd(&outS[ent * CIN + 7 + j], r[u]);
+          if (K3 >= kWave) outS[ent * CIN + SKIP + 7 + j] += r[u];
+          else atomicAdd(&outS[ent * CIN + SKIP + 7 + j], r[u]);
         }
       }
     }
@@ -346,11 +369,18 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
   wave_lds_sync();
 
   if (lane < rows) {
-    float* mine = outS + lane * CIN;
+    float* mine = outS + lane * CIN + SKIP;
     float raw7[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) raw7[i] = raw[(e0 + lane) * CIN + i];
-    const float2 cxy = *reinterpret_cast<const float2*>(coords + 2 * (e0 + lane));
+    for (int i = 0; i < 7; ++i) raw7[i] = raw[(e0 + lane) * CIN + SKIP + i];
+    float2 cxy;
+    float sig_xy[2] = {0.f, 0.f};
+    if (SKIP) {
+      cxy = head_coordinates(dm, p0 + lane, raw[(e0 + lane) * CIN], raw[(e0 + lane) * CIN + 1],
+                             sig_xy);
+    } else {
+      cxy = *reinterpret_cast<const float2*>(coords + 2 * (e0 + lane));
+    }
     LaneGeom g;
     lane_geometry(vw, raw7, cxy.x, cxy.y, smin, smax, eps, g);
     const float mult = vw[kViewMult];
@@ -432,7 +462,12 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
       dcx = fmaf(Ki[3 * a], ddc, dcx);
       dcy = fmaf(Ki[3 * a + 1], ddc, dcy);
     }
-    *reinterpret_cast<float2*>(d_coords + 2 * (e0 + lane)) = make_float2(dcx, dcy);
+    if (SKIP) {   // through (sigmoid(offset) - 0.5) * pixel size
+      mine[-2] = dcx * sig_xy[0] * (1.f - sig_xy[0]) / (float)dm.grid_w;
+      mine[-1] = dcy * sig_xy[1] * (1.f - sig_xy[1]) / (float)dm.grid_h;
+    } else {
+      *reinterpret_cast<float2*>(d_coords + 2 * (e0 + lane)) = make_float2(dcx, dcy);
+    }
     // SH: D^T and the mask, in place
     const float* D = vw + kViewD;
 #pragma unroll 1
@@ -475,32 +510,37 @@ int launch_adapter_views(int n_views, int sh_degree, int img_h, int img_w, const
   return PS_OK;
 }
 
-static size_t adapter_lds(int deg, int spp) {
-  const int cin = 7 + 3 * (deg + 1) * (deg + 1);
+static size_t adapter_lds(int deg, int spp, int skip) {
+  const int cin = skip + 7 + 3 * (deg + 1) * (deg + 1);
   return (size_t)kEntries * (cin + 12 * spp) * sizeof(float);
 }
 
+// head = {surfaces, grid_w, grid_h} selects the head layout (coords unused), nullptr the plain one
 int launch_adapter_forward(int n_views, int rp, int spp, int sh_degree, float smin, float smax,
                            float eps, const float* views, const float* coords,
                            const float* depths, const float* raw, float* means, float* cov,
-                           float* harmonics, hipStream_t st) {
-  if (sh_degree < 0 || sh_degree > 4 || spp < 1 || adapter_lds(sh_degree, spp) > 160 * 1024)
+                           float* harmonics, const int* head, hipStream_t st) {
+  const int skip = head ? 2 : 0;
+  if (sh_degree < 0 || sh_degree > 4 || spp < 1 || adapter_lds(sh_degree, spp, skip) > 160 * 1024)
     return PS_ERR_UNSUPPORTED;
-  const AdapterDims dm{n_views, rp, spp, (sh_degree + 1) * (sh_degree + 1)};
+  const AdapterDims dm{n_views, rp, spp, (sh_degree + 1) * (sh_degree + 1),
+                       head ? head[0] : 1, head ? head[1] : 1, head ? head[2] : 1};
   dim3 grid((rp + kEntries - 1) / kEntries, n_views), block(kWave);
-  const size_t sm = adapter_lds(sh_degree, spp);
-#define PS_GO(D)                                                                              \
+  const size_t sm = adapter_lds(sh_degree, spp, skip);
+#define PS_GO2(D, SK)                                                                         \
   do {                                                                                        \
-    (void)hipFuncSetAttribute((const void*)adapter_forward_kernel<D>,                         \
+    (void)hipFuncSetAttribute((const void*)adapter_forward_kernel<D, SK>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);           \
-    hipLaunchKernelGGL(adapter_forward_kernel<D>, grid, block, sm, st, dm, smin, smax, eps,   \
-                       views, coords, depths, raw, means, cov, harmonics);                    \
+    hipLaunchKernelGGL((adapter_forward_kernel<D, SK>), grid, block, sm, st, dm, smin, smax,  \
+                       eps, views, coords, depths, raw, means, cov, harmonics);               \
   } while (0)
+#define PS_GO(D) do { if (skip) PS_GO2(D, 2); else PS_GO2(D, 0); } while (0)
   switch (sh_degree) {
     case 0: PS_GO(0); break; case 1: PS_GO(1); break; case 2: PS_GO(2); break;
     case 3: PS_GO(3); break; default: PS_GO(4); break;
   }
 #undef PS_GO
+#undef PS_GO2
   return PS_OK;
 }
 
@@ -508,25 +548,29 @@ int launch_adapter_backward(int n_views, int rp, int spp, int sh_degree, float s
                             float eps, const float* views, const float* coords,
                             const float* depths, const float* raw, const float* d_means,
                             const float* d_cov, const float* d_harmonics, float* d_raw,
-                            float* d_depths, float* d_coords, hipStream_t st) {
-  if (sh_degree < 0 || sh_degree > 4 || spp < 1 || adapter_lds(sh_degree, spp) > 160 * 1024)
+                            float* d_depths, float* d_coords, const int* head, hipStream_t st) {
+  const int skip = head ? 2 : 0;
+  if (sh_degree < 0 || sh_degree > 4 || spp < 1 || adapter_lds(sh_degree, spp, skip) > 160 * 1024)
     return PS_ERR_UNSUPPORTED;
-  const AdapterDims dm{n_views, rp, spp, (sh_degree + 1) * (sh_degree + 1)};
+  const AdapterDims dm{n_views, rp, spp, (sh_degree + 1) * (sh_degree + 1),
+                       head ? head[0] : 1, head ? head[1] : 1, head ? head[2] : 1};
   dim3 grid((rp + kEntries - 1) / kEntries, n_views), block(kWave);
-  const size_t sm = adapter_lds(sh_degree, spp);
-#define PS_GO(D)                                                                              \
+  const size_t sm = adapter_lds(sh_degree, spp, skip);
+#define PS_GO2(D, SK)                                                                         \
   do {                                                                                        \
-    (void)hipFuncSetAttribute((const void*)adapter_backward_kernel<D>,                        \
+    (void)hipFuncSetAttribute((const void*)adapter_backward_kernel<D, SK>,                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);           \
-    hipLaunchKernelGGL(adapter_backward_kernel<D>, grid, block, sm, st, dm, smin, smax, eps,  \
-                       views, coords, depths, raw, d_means, d_cov, d_harmonics, d_raw,        \
+    hipLaunchKernelGGL((adapter_backward_kernel<D, SK>), grid, block, sm, st, dm, smin, smax, \
+                       eps, views, coords, depths, raw, d_means, d_cov, d_harmonics, d_raw,   \
                        d_depths, d_coords);                                                   \
   } while (0)
+#define PS_GO(D) do { if (skip) PS_GO2(D, 2); else PS_GO2(D, 0); } while (0)
   switch (sh_degree) {
     case 0: PS_GO(0); break; case 1: PS_GO(1); break; case 2: PS_GO(2); break;
     case 3: PS_GO(3); break; default: PS_GO(4); break;
   }
 #undef PS_GO
+#undef PS_GO2
   return PS_OK;
 }
 

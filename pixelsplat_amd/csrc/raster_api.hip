@@ -365,7 +365,7 @@ int ps_gaussian_adapter_forward(int32_t n_views, int32_t entries_per_view, int32
   Scope sc(G_ADAPTER_FWD, (hipStream_t)stream);
   if (int rc = launch_adapter_forward(n_views, entries_per_view, spp, sh_degree, scale_min,
                                       scale_max, eps, views, coordinates, depths, raw, means,
-                                      covariances, harmonics, (hipStream_t)stream))
+                                      covariances, harmonics, nullptr, (hipStream_t)stream))
     return rc;
   return check_launch();
 }
@@ -384,7 +384,7 @@ int ps_gaussian_adapter_backward(int32_t n_views, int32_t entries_per_view, int3
   if (int rc = launch_adapter_backward(n_views, entries_per_view, spp, sh_degree, scale_min,
                                        scale_max, eps, views, coordinates, depths, raw, d_means,
                                        d_covariances, d_harmonics, d_raw, d_depths, d_coordinates,
-                                       (hipStream_t)stream))
+                                       nullptr, (hipStream_t)stream))
     return rc;
   return check_launch();
 }
@@ -477,6 +477,44 @@ int ps_depth_smoothness_backward(const PsDepthLossDesc* desc, const float* depth
   Scope sc(G_LOSS, (hipStream_t)stream);
   if (int rc = launch_depth_smoothness_backward(*desc, depth, near, far, target_image, d_loss,
                                                 d_depth, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_gaussian_head_forward(int32_t n_views, int32_t image_h, int32_t image_w, int32_t surfaces,
+                             int32_t spp, int32_t sh_degree, float scale_min, float scale_max,
+                             float eps, const float* views, const float* depths,
+                             const float* head_rows, float* means, float* covariances,
+                             float* harmonics, void* stream) {
+  if (n_views <= 0 || image_h <= 0 || image_w <= 0 || surfaces <= 0 || spp <= 0 || !views ||
+      !depths || !head_rows || !means || !covariances || !harmonics)
+    return PS_ERR_BAD_ARG;
+  const int head[3] = {surfaces, image_w, image_h};
+  Scope sc(G_ADAPTER_FWD, (hipStream_t)stream);
+  if (int rc = launch_adapter_forward(n_views, image_h * image_w * surfaces, spp, sh_degree,
+                                      scale_min, scale_max, eps, views, nullptr, depths,
+                                      head_rows, means, covariances, harmonics, head,
+                                      (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_gaussian_head_backward(int32_t n_views, int32_t image_h, int32_t image_w, int32_t surfaces,
+                              int32_t spp, int32_t sh_degree, float scale_min, float scale_max,
+                              float eps, const float* views, const float* depths,
+                              const float* head_rows, const float* d_means,
+                              const float* d_covariances, const float* d_harmonics,
+                              float* d_head_rows, float* d_depths, void* stream) {
+  if (n_views <= 0 || image_h <= 0 || image_w <= 0 || surfaces <= 0 || spp <= 0 || !views ||
+      !depths || !head_rows || !d_means || !d_covariances || !d_harmonics || !d_head_rows ||
+      !d_depths)
+    return PS_ERR_BAD_ARG;
+  const int head[3] = {surfaces, image_w, image_h};
+  Scope sc(G_ADAPTER_BWD, (hipStream_t)stream);
+  if (int rc = launch_adapter_backward(n_views, image_h * image_w * surfaces, spp, sh_degree,
+                                       scale_min, scale_max, eps, views, nullptr, depths,
+                                       head_rows, d_means, d_covariances, d_harmonics,
+                                       d_head_rows, d_depths, nullptr, head, (hipStream_t)stream))
     return rc;
   return check_launch();
 }

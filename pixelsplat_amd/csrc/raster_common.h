@@ -173,12 +173,12 @@ int launch_adapter_views(int n_views, int sh_degree, int img_h, int img_w, const
 int launch_adapter_forward(int n_views, int rp, int spp, int sh_degree, float smin, float smax,
                            float eps, const float* views, const float* coords,
                            const float* depths, const float* raw, float* means, float* cov,
-                           float* harmonics, hipStream_t st);
+                           float* harmonics, const int* head, hipStream_t st);
 int launch_adapter_backward(int n_views, int rp, int spp, int sh_degree, float smin, float smax,
                             float eps, const float* views, const float* coords,
                             const float* depths, const float* raw, const float* d_means,
                             const float* d_cov, const float* d_harmonics, float* d_raw,
-                            float* d_depths, float* d_coords, hipStream_t st);
+                            float* d_depths, float* d_coords, const int* head, hipStream_t st);
 int launch_depth_sampler_forward(const PsDepthSamplerDesc& d, const float* projected,
                                  const float* near, const float* far, const float* uniforms,
                                  float* depth, float* opacity, int32_t* index, hipStream_t st);

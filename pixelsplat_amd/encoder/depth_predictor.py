@@ -117,7 +117,10 @@ class DepthPredictorMonocular(nn.Module):
         self.to_pdf = nn.Softmax(dim=-1)
         self.to_offset = nn.Sigmoid()
 
-    def _run(self, features, near, far, deterministic, gaussians_per_pixel, exponent, scale):
+    def _run(self, features, near, far, deterministic, gaussians_per_pixel, exponent, scale,
+             activated=None):
+        """`activated` = relu(features) as [b * v * r, c] when the caller already has it (the
+        encoder head shares it with `to_gaussians`)."""
         if len(self.to_pdf._forward_hooks) or len(self.to_offset._forward_hooks):
             raise RuntimeError("forward hooks on to_pdf / to_offset are not served by the fused "
                                "depth sampler; read the distribution from `projection` instead")
@@ -125,7 +128,8 @@ class DepthPredictorMonocular(nn.Module):
         # is a GEMM with k = all rays of the batch, which goes to the split-k kernel
         linear = self.projection[1]
         b, v, r, c = features.shape
-        activated = torch.relu(features).reshape(b * v * r, c)
+        if activated is None:
+            activated = torch.relu(features).reshape(b * v * r, c)
         projected = _RayLinear.apply(activated, linear.weight, linear.bias).view(b, v, r, -1)
         uniforms = None
         if not deterministic:
