@@ -263,6 +263,28 @@ def main():
         dep, opa = dp.forward_mapped(dp_feat, dp_near, dp_far, False, 3, 1.0, 1.0 / 3)
         (dep.sum() + opa.sum()).backward()
 
+    # ---- the chain either side of the boundary between (A) and (B): per-pixel features ->
+    # EncoderEpipolarHead (depth sampler + head linear layers + adapter) -> rasterizer -> MSE,
+    # gradients back to the features and the head weights (encoder_epipolar.py:143-214 +
+    # decoder + loss_mse.py); random-init head, so its scene is not the synthetic one above
+    from pixelsplat_amd.encoder import (EncoderEpipolarHead, EncoderEpipolarHeadCfg,
+                                        OpacityMappingCfg)
+    head = EncoderEpipolarHead(EncoderEpipolarHeadCfg(
+        d_feature=d_feat, num_monocular_samples=32, num_surfaces=1, predict_opacity=False,
+        gaussians_per_pixel=3, gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 4),
+        opacity_mapping=OpacityMappingCfg(0.0, 0.0, 1), use_transmittance=False)).to(dev)
+    head_ctx = dict(extrinsics=c_ext, intrinsics=c_intr, near=ctx.near.to(dev), far=ctx.far.to(dev))
+    head_feat = torch.randn(b, 2, *hw, d_feat, device=dev).permute(0, 1, 4, 2, 3).requires_grad_(True)
+
+    def step_chain():
+        head_feat.grad = None
+        for p_ in head.parameters():
+            p_.grad = None
+        gs = head(head_feat, head_ctx, global_step=0)
+        img_ = render_cuda(ext, intr, near, far, hw, bg, gs.means, gs.covariances, gs.harmonics,
+                           gs.opacities, views_per_scene=v)
+        mse_and_psnr(img_, tgt_img, 1.0)[0].backward()
+
     def timed(fn, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -306,6 +328,12 @@ def main():
     ms_ga = timed(step_adapter, args.steps)
     ms_dp = timed(step_depth, args.steps)
     lib.ps_profile_enable(0)
+    try:
+        step_chain()
+        ms_chain = timed(step_chain, args.steps)
+    except RuntimeError as err:   # e.g. PS_ERR_CAPACITY for a degenerate random scene
+        print(f"[bench] chain probe skipped: {err}", file=sys.stderr)
+        ms_chain = None
     side_ms = (C.c_double * ng)()
     side_n = (C.c_int64 * ng)()
     _lib.check(lib.ps_profile_collect(side_ms, side_n), "ps_profile_collect")
@@ -381,6 +409,8 @@ def main():
                 # rank 3: features -> (depth, opacity): ReLU + Linear (library GEMM, split-k
                 # weight gradient) + ps_depth_sampler_*, fwd + bwd; not part of `value`
                 "depth_predictor_only_ms_per_step": round(ms_dp, 3),
+                # features -> head -> Gaussians -> 28 rendered views -> MSE and back
+                "head_decoder_loss_chain_ms_per_step": (round(ms_chain, 3) if ms_chain else None),
                 "epipolar_reference_equivalent_tflops": round(
                     3.0 * 2 * (2.0 * RA * (2 * d_feat * 512 + TA * d_feat * 1024 + 2 * 4 * TA * 128))
                     / (ms_a * 1e-3) / 1e12, 1),
