@@ -214,7 +214,7 @@ def main():
         folds = et.fold_layers()
         grad_batch = FeatureGradBatch()
         for (attn, _ff), folded in zip(et.transformer.layers, folds):
-            x = et.fused_layer(attn, x, feat, geo, folded=folded, batch=grad_batch) + x
+            x = et.fused_block(attn, x, feat, geo, folded=folded, batch=grad_batch)
         return x.square().mean()
 
     def path_b():

@@ -364,6 +364,52 @@ int ps_depth_smoothness_backward(const PsDepthLossDesc* desc, const float* depth
                                  const float* near, const float* far, const float* target_image,
                                  const float* d_loss, float* d_depth, void* stream);
 
+/* ---- Folded weights of one epipolar cross-attention layer -----------------------
+ * The linear maps either side of ps_epipolar_attention_* -- to_q / to_kv / to_out of
+ * src/model/transformer/attention.py:45-52, the depth-encoding Linear of
+ * epipolar_transformer.py:67-70 and the view embeddings of :126-131 -- folded into the two
+ * matrices the per-ray GEMMs use, rows laid out per head ([q~ (kv_dim) | u (2 octaves) |
+ * e (other_views) | pad to 4] = Lh rows per head):
+ *   w_in  float[heads * Lh][q_dim],  w_o_t float[heads * Lh][out_dim],  bias float[out_dim]
+ * from w_q [heads*head_dim][q_dim], w_kv [2*heads*head_dim][kv_dim], w_out [out_dim][heads*head_dim],
+ * b_out [out_dim] or NULL, depth_w [kv_dim][2*octaves], depth_b [kv_dim], view_emb
+ * [other_views][kv_dim] or NULL (other_views = 0).  scratch (ps_fold_scratch_floats floats) is
+ * written by the forward and read by the backward; the backward needs a second buffer of the
+ * same size.  Gradient outputs mirror the inputs (g_b_out / g_view_emb may be NULL). */
+typedef struct PsFoldDesc {
+  int32_t heads, head_dim, kv_dim, q_dim, out_dim, octaves, other_views;
+} PsFoldDesc;
+size_t ps_fold_scratch_floats(const PsFoldDesc* desc);
+int ps_fold_attention_weights(const PsFoldDesc* desc, const float* w_q, const float* w_kv,
+                              const float* w_out, const float* b_out, const float* depth_w,
+                              const float* depth_b, const float* view_emb, float* w_in,
+                              float* w_o_t, float* bias, float* scratch, void* stream);
+int ps_fold_attention_weights_backward(const PsFoldDesc* desc, const float* w_q, const float* w_kv,
+                                       const float* w_out, const float* b_out,
+                                       const float* depth_w, const float* depth_b,
+                                       const float* view_emb, const float* scratch,
+                                       const float* d_w_in, const float* d_w_o_t,
+                                       const float* d_bias, float* back_scratch, float* g_w_q,
+                                       float* g_w_kv, float* g_w_out, float* g_b_out,
+                                       float* g_depth_w, float* g_depth_b, float* g_view_emb,
+                                       void* stream);
+
+/* LayerNorm over the last dimension of x [rows][dim] (the PreNorm of the cross-attention
+ * layers, src/model/transformer/pre_norm.py:34-35), fp32, dim % 4 == 0 and dim <= 512 (else
+ * PS_ERR_UNSUPPORTED).  mean / rstd [rows] are saved for the backward; the backward's
+ * workspace holds ps_layer_norm_workspace_floats(rows, dim) floats; d_gamma / d_beta are
+ * summed in a fixed order (deterministic).  d_residual: the gradient reaching x through the
+ * residual branch of `x + f(LayerNorm(x))`, added in the same pass. */
+size_t ps_layer_norm_workspace_floats(int32_t rows, int32_t dim);
+int ps_layer_norm_forward(int32_t rows, int32_t dim, float eps, const float* x,
+                          const float* gamma, const float* beta, float* y, float* mean,
+                          float* rstd, void* stream);
+int ps_layer_norm_backward(int32_t rows, int32_t dim, const float* x, const float* gamma,
+                           const float* mean, const float* rstd, const float* dy,
+                           const float* d_residual /* NULL, or [rows][dim] added to dx */,
+                           float* dx, float* d_gamma, float* d_beta, float* workspace,
+                           void* stream);
+
 /* Feature-map gradient of n_layers (1 or 2) attention layers that share the geometry, in ONE
  * scatter pass: dfmap = sum over layers of the gradient ps_epipolar_attention_backward would
  * write for that layer (call that function with dfmap = NULL and hand its ds here).  qt, attn,

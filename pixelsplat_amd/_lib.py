@@ -48,6 +48,11 @@ class PsDepthSamplerDesc(C.Structure):
         ("opacity_exponent", C.c_float), ("opacity_scale", C.c_float)]
 
 
+class PsFoldDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("heads", "head_dim", "kv_dim", "q_dim", "out_dim",
+                                         "octaves", "other_views")]
+
+
 class PsDepthLossDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_images", "height", "width", "channels",
                                          "use_second_derivative", "use_sigma")] + [
@@ -66,6 +71,8 @@ EXPORTS = [
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
     "ps_gaussian_head_forward", "ps_gaussian_head_backward",
     "ps_depth_sampler_forward", "ps_depth_sampler_backward",
+    "ps_layer_norm_workspace_floats", "ps_layer_norm_forward", "ps_layer_norm_backward",
+    "ps_fold_scratch_floats", "ps_fold_attention_weights", "ps_fold_attention_weights_backward",
     "ps_image_mse_workspace_bytes", "ps_image_mse", "ps_depth_smoothness_workspace_bytes",
     "ps_depth_smoothness_forward", "ps_depth_smoothness_backward",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
@@ -147,6 +154,19 @@ def load():
     lib.ps_depth_sampler_forward.restype = C.c_int
     lib.ps_depth_sampler_backward.argtypes = [pd] + [vp] * 8
     lib.ps_depth_sampler_backward.restype = C.c_int
+    lib.ps_layer_norm_workspace_floats.argtypes = [C.c_int32, C.c_int32]
+    lib.ps_layer_norm_workspace_floats.restype = C.c_size_t
+    lib.ps_layer_norm_forward.argtypes = [C.c_int32, C.c_int32, C.c_float] + [vp] * 7
+    lib.ps_layer_norm_forward.restype = C.c_int
+    lib.ps_layer_norm_backward.argtypes = [C.c_int32, C.c_int32] + [vp] * 11
+    lib.ps_layer_norm_backward.restype = C.c_int
+    pf = C.POINTER(PsFoldDesc)
+    lib.ps_fold_scratch_floats.argtypes = [pf]
+    lib.ps_fold_scratch_floats.restype = C.c_size_t
+    lib.ps_fold_attention_weights.argtypes = [pf] + [vp] * 12
+    lib.ps_fold_attention_weights.restype = C.c_int
+    lib.ps_fold_attention_weights_backward.argtypes = [pf] + [vp] * 20
+    lib.ps_fold_attention_weights_backward.restype = C.c_int
     lib.ps_image_mse_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.ps_image_mse_workspace_bytes.restype = C.c_size_t
     lib.ps_image_mse.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_float, vp, vp, vp, vp,

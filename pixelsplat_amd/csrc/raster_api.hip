@@ -519,6 +519,78 @@ int ps_gaussian_head_backward(int32_t n_views, int32_t image_h, int32_t image_w,
   return check_launch();
 }
 
+namespace {
+bool fold_desc_ok(const PsFoldDesc* d) {
+  return d && d->heads > 0 && d->head_dim > 0 && d->kv_dim > 0 && d->q_dim > 0 && d->out_dim > 0 &&
+         d->octaves >= 0 && d->other_views >= 0;
+}
+}  // namespace
+
+size_t ps_fold_scratch_floats(const PsFoldDesc* desc) {
+  return fold_desc_ok(desc) ? fold_scratch_floats(*desc) : 0;
+}
+
+int ps_fold_attention_weights(const PsFoldDesc* desc, const float* w_q, const float* w_kv,
+                              const float* w_out, const float* b_out, const float* depth_w,
+                              const float* depth_b, const float* view_emb, float* w_in,
+                              float* w_o_t, float* bias, float* scratch, void* stream) {
+  if (!fold_desc_ok(desc) || !w_q || !w_kv || !w_out || !depth_w || !depth_b || !w_in || !w_o_t ||
+      !bias || !scratch || (desc->other_views > 0 && !view_emb))
+    return PS_ERR_BAD_ARG;
+  if (int rc = launch_fold_forward(*desc, w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb,
+                                   w_in, w_o_t, bias, scratch, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_fold_attention_weights_backward(const PsFoldDesc* desc, const float* w_q, const float* w_kv,
+                                       const float* w_out, const float* b_out,
+                                       const float* depth_w, const float* depth_b,
+                                       const float* view_emb, const float* scratch,
+                                       const float* d_w_in, const float* d_w_o_t,
+                                       const float* d_bias, float* back_scratch, float* g_w_q,
+                                       float* g_w_kv, float* g_w_out, float* g_b_out,
+                                       float* g_depth_w, float* g_depth_b, float* g_view_emb,
+                                       void* stream) {
+  if (!fold_desc_ok(desc) || !w_q || !w_kv || !w_out || !depth_w || !depth_b || !scratch ||
+      !d_w_in || !d_w_o_t || !d_bias || !back_scratch || !g_w_q || !g_w_kv || !g_w_out ||
+      !g_depth_w || !g_depth_b || (desc->other_views > 0 && (!view_emb || !g_view_emb)))
+    return PS_ERR_BAD_ARG;
+  if (int rc = launch_fold_backward(*desc, w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb,
+                                    scratch, d_w_in, d_w_o_t, d_bias, back_scratch, g_w_q, g_w_kv,
+                                    g_w_out, g_b_out, g_depth_w, g_depth_b, g_view_emb,
+                                    (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+size_t ps_layer_norm_workspace_floats(int32_t rows, int32_t dim) {
+  return rows > 0 && dim > 0 ? layer_norm_workspace_floats(rows, dim) : 0;
+}
+
+int ps_layer_norm_forward(int32_t rows, int32_t dim, float eps, const float* x,
+                          const float* gamma, const float* beta, float* y, float* mean,
+                          float* rstd, void* stream) {
+  if (rows <= 0 || dim <= 0 || !x || !gamma || !beta || !y || !mean || !rstd) return PS_ERR_BAD_ARG;
+  if (int rc = launch_layer_norm_forward(rows, dim, eps, x, gamma, beta, y, mean, rstd,
+                                         (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_layer_norm_backward(int32_t rows, int32_t dim, const float* x, const float* gamma,
+                           const float* mean, const float* rstd, const float* dy,
+                           const float* d_residual, float* dx, float* d_gamma, float* d_beta,
+                           float* workspace, void* stream) {
+  if (rows <= 0 || dim <= 0 || !x || !gamma || !mean || !rstd || !dy || !dx || !d_gamma ||
+      !d_beta || !workspace)
+    return PS_ERR_BAD_ARG;
+  if (int rc = launch_layer_norm_backward(rows, dim, x, gamma, mean, rstd, dy, d_residual, dx, d_gamma, d_beta,
+                                          workspace, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
 int ps_invert_cameras(int32_t n, const float* c2w, const float* k, float* w2c, float* k_inv,
                       void* stream) {
   if (n <= 0 || !c2w || !k || !w2c || !k_inv) return PS_ERR_BAD_ARG;

@@ -197,6 +197,26 @@ int launch_depth_smoothness_forward(const PsDepthLossDesc& d, const float* depth
 int launch_depth_smoothness_backward(const PsDepthLossDesc& d, const float* depth,
                                      const float* near, const float* far, const float* image,
                                      const float* d_loss, float* d_depth, hipStream_t st);
+size_t fold_scratch_floats(const PsFoldDesc& d);
+int launch_fold_forward(const PsFoldDesc& d, const float* w_q, const float* w_kv,
+                        const float* w_out, const float* b_out, const float* depth_w,
+                        const float* depth_b, const float* view_emb, float* w_in, float* w_o_t,
+                        float* bias, float* scratch, hipStream_t st);
+int launch_fold_backward(const PsFoldDesc& d, const float* w_q, const float* w_kv,
+                         const float* w_out, const float* b_out, const float* depth_w,
+                         const float* depth_b, const float* view_emb, const float* scratch,
+                         const float* d_w_in, const float* d_w_o_t, const float* d_bias,
+                         float* back_scratch, float* g_w_q, float* g_w_kv, float* g_w_out,
+                         float* g_b_out, float* g_depth_w, float* g_depth_b, float* g_view_emb,
+                         hipStream_t st);
+size_t layer_norm_workspace_floats(int rows, int dim);
+int launch_layer_norm_forward(int rows, int dim, float eps, const float* x, const float* gamma,
+                              const float* beta, float* y, float* mean, float* rstd,
+                              hipStream_t st);
+int launch_layer_norm_backward(int rows, int dim, const float* x, const float* gamma,
+                               const float* mean, const float* rstd, const float* dy,
+                               const float* d_residual, float* dx, float* d_gamma, float* d_beta,
+                               float* workspace, hipStream_t st);
 void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
                            hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor, nn
 
 from ..epipolar import (FeatureGradBatch, fold_attention_weights, fused_cross_attention,
-                        gather_features)
+                        gather_features, layer_norm, layer_norm_fork)
 from .epipolar_sampler import EpipolarSampler, EpipolarSampling
 from .transformer import Transformer
 
@@ -164,22 +164,38 @@ class EpipolarTransformer(nn.Module):
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
         side.wait_stream(main)
+        folds = []
         with torch.cuda.stream(side):
-            folds = [fold_attention_weights(**self._layer_weights(attn, view_emb))
-                     for attn, _ in self.transformer.layers]
-        main.wait_stream(side)
-        for f in folds:
-            for t in f:
-                t.record_stream(main)
+            for attn, _ in self.transformer.layers:
+                f = fold_attention_weights(**self._layer_weights(attn, view_emb))
+                done = torch.cuda.Event()
+                done.record(side)
+                for t in f:
+                    t.record_stream(main)
+                folds.append((*f, done))   # fused_layer waits for `done` where it needs f
         return folds
 
     def fused_layer(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None,
                     folded=None, batch=None) -> Tensor:
         """PreNorm(Attention)(x, z=kv) (pre_norm.py:34-35, attention.py:54-70) on the HIP path;
         `attn` is one `layer[0]` of `self.transformer.layers`, fmap is channels-last."""
-        return fused_cross_attention(attn.norm(x), fmap, geo, octaves=self.cfg.num_octaves,
+        if folded is not None and len(folded) == 4:
+            torch.cuda.current_stream().wait_event(folded[3])
+            folded = folded[:3]
+        return fused_cross_attention(layer_norm(x, attn.norm), fmap, geo, octaves=self.cfg.num_octaves,
                                      folded=folded, batch=batch,
                                      **self._layer_weights(attn, view_emb))
+
+    def fused_block(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None,
+                    folded=None, batch=None) -> Tensor:
+        """`PreNorm(Attention)(x, z=kv) + x` (transformer.py:68): fused_layer plus the residual,
+        with the residual's gradient folded into the LayerNorm backward."""
+        if folded is not None and len(folded) == 4:
+            torch.cuda.current_stream().wait_event(folded[3])
+            folded = folded[:3]
+        xn, xr = layer_norm_fork(x, attn.norm)
+        return fused_cross_attention(xn, fmap, geo, octaves=self.cfg.num_octaves, folded=folded,
+                                     batch=batch, **self._layer_weights(attn, view_emb)) + xr
 
     def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor, materialize_sampling: bool = False,
@@ -218,10 +234,9 @@ class EpipolarTransformer(nn.Module):
                     if view_emb is not None:
                         kv = kv + view_emb[None, None, :, None, None, :]
                     kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
-                y = attn(x, z=kv)
+                x = attn(x, z=kv) + x
             else:
-                y = self.fused_layer(attn, x, fmap, geo, view_emb, folded, grad_batch)
-            x = y + x
+                x = self.fused_block(attn, x, fmap, geo, view_emb, folded, grad_batch)
             x = ff(x, b=b, v=v, h=h, w=w) + x
         features = x.reshape(b, v, h, w, c).permute(0, 1, 4, 2, 3)
 

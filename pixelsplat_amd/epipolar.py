@@ -137,6 +137,69 @@ class _RayLinear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LayerNorm(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension on ps_layer_norm_* (csrc/layer_norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, fork):
+        lib = _lib.load()
+        dim = x.shape[-1]
+        x2 = x.reshape(-1, dim).contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        _lib.check(lib.ps_layer_norm_forward(rows, dim, C.c_float(eps), _p(x2), _p(g), _p(b), _p(y),
+                                             _p(stats[0]), _p(stats[1]), _stream()),
+                   "ps_layer_norm_forward")
+        ctx.save_for_backward(x2, g, stats)
+        if fork:   # second output: x itself, for the residual branch (its gradient is added to
+            return y.view(x.shape), x.view_as(x)   # dx inside the backward kernel)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy, d_res=None):
+        lib = _lib.load()
+        x2, g, stats = ctx.saved_tensors
+        rows, dim = x2.shape
+        if dy is None:
+            dy = torch.zeros_like(x2)
+        dy2 = dy.reshape(rows, dim).contiguous()
+        res = None if d_res is None else d_res.reshape(rows, dim).contiguous()
+        dx = torch.empty_like(x2)
+        dgb = torch.empty((2, dim), dtype=torch.float32, device=x2.device)
+        ws = torch.empty((lib.ps_layer_norm_workspace_floats(rows, dim),), dtype=torch.float32,
+                         device=x2.device)
+        _lib.check(lib.ps_layer_norm_backward(rows, dim, _p(x2), _p(g), _p(stats[0]), _p(stats[1]),
+                                              _p(dy2), _p(res), _p(dx), _p(dgb[0]), _p(dgb[1]),
+                                              _p(ws), _stream()), "ps_layer_norm_backward")
+        return dx.view(dy.shape), dgb[0], dgb[1], None, None
+
+
+def _ln_kernel_applies(x: Tensor, norm: torch.nn.LayerNorm) -> bool:
+    dim = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and norm.elementwise_affine
+            and norm.bias is not None and tuple(norm.normalized_shape) == (dim,)
+            and dim % 4 == 0 and dim <= 512 and x.numel() > 0)
+
+
+def layer_norm(x: Tensor, norm: torch.nn.LayerNorm) -> Tensor:
+    """`norm(x)` for an nn.LayerNorm over the last dimension; the HIP kernels when they apply
+    (GPU fp32, affine, dim % 4 == 0, dim <= 512), the library op otherwise."""
+    if _ln_kernel_applies(x, norm):
+        return _LayerNorm.apply(x, norm.weight, norm.bias, float(norm.eps), False)
+    return norm(x)
+
+
+def layer_norm_fork(x: Tensor, norm: torch.nn.LayerNorm):
+    """(norm(x), x) for a pre-norm residual block `x + f(norm(x))`: use the second value for the
+    residual add and the gradient arriving through it is added to dx inside the LayerNorm
+    backward kernel instead of a separate accumulation pass."""
+    if _ln_kernel_applies(x, norm):
+        return _LayerNorm.apply(x, norm.weight, norm.bias, float(norm.eps), True)
+    return norm(x), x
+
+
 def _pad4(n: int) -> int:
     return (n + 3) & ~3
 
@@ -259,9 +322,79 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         return (None, None, None, dfmap, None, None, None, dqin, None)
 
 
+class _FoldWeights(torch.autograd.Function):
+    """fold_attention_weights on the GPU: two launches forward, two backward
+    (csrc/fold_weights.hip) instead of ~40 tiny library launches each way."""
+
+    @staticmethod
+    def forward(ctx, heads, w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb):
+        lib = _lib.load()
+        tensors = [t if t is None else t.detach().to(torch.float32).contiguous()
+                   for t in (w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb)]
+        w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb = tensors
+        inner, d_in = w_q.shape
+        c, d_out, p2 = w_kv.shape[1], w_out.shape[0], depth_w.shape[1]
+        ov = 0 if view_emb is None else view_emb.shape[0]
+        desc = _lib.PsFoldDesc(heads, inner // heads, c, d_in, d_out, p2 // 2, ov)
+        lh = _pad4(c + p2 + ov)
+        f32 = dict(dtype=torch.float32, device=w_q.device)
+        w_in = torch.empty((heads * lh, d_in), **f32)
+        w_o_t = torch.empty((heads * lh, d_out), **f32)
+        bias = torch.empty((d_out,), **f32)
+        scratch = torch.empty((lib.ps_fold_scratch_floats(C.byref(desc)),), **f32)
+        _lib.check(lib.ps_fold_attention_weights(
+            C.byref(desc), _p(w_q), _p(w_kv), _p(w_out), _p(b_out), _p(depth_w), _p(depth_b),
+            _p(view_emb), _p(w_in), _p(w_o_t), _p(bias), _p(scratch), _stream()),
+            "ps_fold_attention_weights")
+        ctx.desc = desc
+        ctx.has = (b_out is not None, view_emb is not None)
+        ctx.save_for_backward(*[t for t in tensors if t is not None], scratch)
+        return w_in, w_o_t, bias
+
+    @staticmethod
+    def backward(ctx, d_w_in, d_w_o_t, d_bias):
+        lib = _lib.load()
+        saved = list(ctx.saved_tensors)
+        scratch = saved.pop()
+        has_b, has_e = ctx.has
+        it = iter(saved)
+        w_q, w_kv, w_out = next(it), next(it), next(it)
+        b_out = next(it) if has_b else None
+        depth_w, depth_b = next(it), next(it)
+        view_emb = next(it) if has_e else None
+        grads = [torch.empty_like(t) if t is not None else None
+                 for t in (w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb)]
+        h_lh = w_kv.shape[1] + depth_w.shape[1] + (view_emb.shape[0] if has_e else 0)
+        rows = ctx.desc.heads * _pad4(h_lh)
+        f32 = dict(dtype=torch.float32, device=w_q.device)
+        d_w_in = (torch.zeros((rows, w_q.shape[1]), **f32) if d_w_in is None
+                  else d_w_in.contiguous())
+        d_w_o_t = (torch.zeros((rows, w_out.shape[0]), **f32) if d_w_o_t is None
+                   else d_w_o_t.contiguous())
+        d_bias = torch.zeros((w_out.shape[0],), **f32) if d_bias is None else d_bias.contiguous()
+        back = torch.empty_like(scratch)
+        _lib.check(lib.ps_fold_attention_weights_backward(
+            C.byref(ctx.desc), _p(w_q), _p(w_kv), _p(w_out), _p(b_out), _p(depth_w), _p(depth_b),
+            _p(view_emb), _p(scratch), _p(d_w_in), _p(d_w_o_t), _p(d_bias), _p(back),
+            *[_p(g) for g in grads], _stream()), "ps_fold_attention_weights_backward")
+        return (None, *grads)
+
+
 def fold_attention_weights(*, w_q: Tensor, w_kv: Tensor, w_out: Tensor, b_out: Tensor | None,
                            heads: int, depth_w: Tensor, depth_b: Tensor,
                            view_emb: Tensor | None = None):
+    """Every linear map on either side of the kernel folded into ONE weight matrix per side
+    (GPU tensors: ps_fold_attention_weights; otherwise the torch statement of the same
+    algebra, fold_attention_weights_torch)."""
+    if w_q.is_cuda:
+        return _FoldWeights.apply(heads, w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb)
+    return fold_attention_weights_torch(w_q=w_q, w_kv=w_kv, w_out=w_out, b_out=b_out, heads=heads,
+                                        depth_w=depth_w, depth_b=depth_b, view_emb=view_emb)
+
+
+def fold_attention_weights_torch(*, w_q: Tensor, w_kv: Tensor, w_out: Tensor,
+                                 b_out: Tensor | None, heads: int, depth_w: Tensor,
+                                 depth_b: Tensor, view_emb: Tensor | None = None):
     """Every linear map on either side of the kernel folded into ONE weight matrix per side.
     With A = [I_c; W_d^T; E] (rows: identity, depth-encoding weights, view embeddings):
         [q~_h; u_h; e_h] = (A W_k,h^T) W_q,h x                       -> w_in   [H*Lh, d]

@@ -333,3 +333,67 @@ def test_invert_cameras(gpu_device):
     ref_k = torch.linalg.inv(k.double().cpu())
     assert (w2c.cpu().double() - ref_w).abs().max() < 1e-6 * ref_w.abs().max()
     assert (k_inv.cpu().double() - ref_k).abs().max() < 1e-6 * ref_k.abs().max()
+
+
+@pytest.mark.parametrize("heads,dh,c,d,d_out,octaves,ov,bias", [
+    (4, 32, 128, 128, 128, 10, 0, True), (2, 8, 20, 12, 16, 3, 2, True), (3, 5, 17, 9, 17, 1, 1, False)])
+def test_fold_weights_kernels_vs_torch(gpu_device, heads, dh, c, d, d_out, octaves, ov, bias):
+    """ps_fold_attention_weights (+ backward) against the torch statement of the same algebra
+    (fold_attention_weights_torch, itself checked against the unfused attention on the CPU)."""
+    from pixelsplat_amd.epipolar import fold_attention_weights, fold_attention_weights_torch
+
+    torch.manual_seed(heads * 100 + c)
+    dev = gpu_device
+    inner = heads * dh
+    mk = lambda *s: (torch.randn(*s, device=dev) * 0.3).requires_grad_(True)
+    args = dict(w_q=mk(inner, d), w_kv=mk(2 * inner, c), w_out=mk(d_out, inner),
+                b_out=mk(d_out) if bias else None, depth_w=mk(c, 2 * octaves), depth_b=mk(c),
+                view_emb=mk(ov, c) if ov else None)
+    ref = fold_attention_weights_torch(heads=heads, **args)
+    wts = [torch.randn_like(t) for t in ref]
+    sum((a * b).sum() for a, b in zip(ref, wts)).backward()
+    g_ref = {k: t.grad.clone() for k, t in args.items() if t is not None}
+    for t in args.values():
+        if t is not None:
+            t.grad = None
+    out = fold_attention_weights(heads=heads, **args)
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() < 2e-6 * max(b.abs().max().item(), 1.0)
+    sum((a * b).sum() for a, b in zip(out, wts)).backward()
+    for k, t in args.items():
+        if t is not None:
+            err = (t.grad - g_ref[k]).abs().max().item() / max(g_ref[k].abs().max().item(), 1e-9)
+            assert err < 5e-6, f"{k}: {err:.2e}"
+
+
+@pytest.mark.parametrize("rows,dim", [(57344, 128), (1000, 128), (37, 20), (513, 512), (3, 260)])
+def test_layer_norm_kernels_vs_torch(gpu_device, rows, dim):
+    """ps_layer_norm_* against torch.nn.functional.layer_norm in float64 (the plain fp32
+    reference of this floating-point kernel): 2e-6 on y, 1e-5 on the gradients relative to
+    their largest entry; d_gamma / d_beta bit-reproducible run to run."""
+    from pixelsplat_amd.epipolar import layer_norm
+
+    torch.manual_seed(rows + dim)
+    dev = gpu_device
+    norm = torch.nn.LayerNorm(dim).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(rows, 1, dim, device=dev) * 2 + 0.7).requires_grad_(True)
+    w = torch.randn(rows, 1, dim, device=dev)
+    y = layer_norm(x, norm)
+    (y * w).sum().backward()
+    got = (y.detach(), x.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone())
+    x.grad = norm.weight.grad = norm.bias.grad = None
+    y2 = layer_norm(x, norm)
+    (y2 * w).sum().backward()
+    assert torch.equal(norm.weight.grad, got[2]) and torch.equal(norm.bias.grad, got[3])
+    xd = x.detach().double().requires_grad_(True)
+    gd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.layer_norm(xd, (dim,), gd, bd, norm.eps)
+    (yd * w.double()).sum().backward()
+    for name, a, b, tol in (("y", got[0], yd.detach(), 2e-6), ("dx", got[1], xd.grad, 1e-5),
+                            ("dgamma", got[2], gd.grad, 1e-5), ("dbeta", got[3], bd.grad, 1e-5)):
+        err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+        assert err < tol, f"{name}: {err:.2e}"
