@@ -166,7 +166,7 @@ def main():
 
     from pixelsplat_amd import _lib
     from pixelsplat_amd.decoder import render_cuda
-    from pixelsplat_amd.loss import mse_and_psnr
+    from pixelsplat_amd.loss import mse_loss
     from pixelsplat_amd.raster import export_bins
     from pixelsplat_amd.synthetic import make_workload
 
@@ -219,7 +219,7 @@ def main():
 
     def path_b():
         img = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v)
-        return mse_and_psnr(img, tgt_img, 1.0)[0]   # LossMse (loss_mse.py:30-31), one pass
+        return mse_loss(img, tgt_img, 1.0)   # LossMse (loss_mse.py:30-31), one pass
 
     def zero_grads():
         for t in (means, cov, sh, op, feat, *a_params):
@@ -283,7 +283,7 @@ def main():
         gs = head(head_feat, head_ctx, global_step=0)
         img_ = render_cuda(ext, intr, near, far, hw, bg, gs.means, gs.covariances, gs.harmonics,
                            gs.opacities, views_per_scene=v)
-        mse_and_psnr(img_, tgt_img, 1.0)[0].backward()
+        mse_loss(img_, tgt_img, 1.0).backward()
 
     def timed(fn, n):
         torch.cuda.synchronize()

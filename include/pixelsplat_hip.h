@@ -59,6 +59,11 @@ typedef enum PsStatus {
                                       scale-invariant renorm of cuda_splatting.py:64-71;
                                       1.0 for the plain per-view boundary)            */
 
+/* PsRasterDesc.flags: the caller has already zeroed the backward temp buffer with
+ * ps_raster_backward_prepare (e.g. on a second stream while the forward's tile kernels, which
+ * are VALU-bound, run), so ps_raster_backward skips its own memset. */
+#define PS_FLAG_BWD_TEMP_ZEROED 1
+
 typedef struct PsRasterDesc {
   int32_t n_scenes;        /* S: independent Gaussian sets                           */
   int32_t views_per_scene; /* views rendered from each set; view v uses scene v / views_per_scene */
@@ -68,7 +73,7 @@ typedef struct PsRasterDesc {
   int32_t sh_coeffs;       /* K stored per channel (>= (deg+1)^2); 0 => colors_precomp */
   int32_t sh_layout;       /* PS_SH_*                                                */
   int32_t cov_layout;      /* PS_COV_*                                               */
-  int32_t reserved;
+  int32_t flags;           /* PS_FLAG_* bits, 0 by default                           */
   /* algorithm constants; ps_raster_default_desc fills them */
   float near_cull;    /* 0.2   */
   float guard;        /* 1.3   */
@@ -140,6 +145,15 @@ int ps_raster_forward_render(const PsRasterDesc* desc, const float* view_params,
                              float* out_color, void* state, size_t state_bytes, void* temp,
                              size_t temp_bytes, uint32_t* point_list, size_t list_capacity,
                              void* stream);
+/* ps_raster_forward_render in its two halves (tile lists, then blending), for hosts that want
+ * to put other work between them -- e.g. ps_raster_backward_prepare on a second stream once
+ * the memory-bound list write is done, under the VALU-bound blend. */
+int ps_raster_forward_bins(const PsRasterDesc* desc, void* state, size_t state_bytes, void* temp,
+                           size_t temp_bytes, uint32_t* point_list, size_t list_capacity,
+                           void* stream);
+int ps_raster_forward_tiles(const PsRasterDesc* desc, const float* view_params, float* out_color,
+                            void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                            const uint32_t* point_list, size_t list_capacity, void* stream);
 
 /* Backward.  Replaces _RasterizeGaussians.backward of the external module.
  *   radii       int32[V][G]  (the forward's out_radii)
@@ -167,6 +181,12 @@ int ps_raster_backward(const PsRasterDesc* desc, const float* means, const float
  * ps_raster_forward.  Returns PS_OK, or PS_ERR_CAPACITY. */
 int ps_raster_check(const PsRasterDesc* desc, const void* state, size_t state_bytes,
                     uint64_t* num_rendered, void* stream);
+
+/* Zeroes the backward temp buffer (the accumulators ps_raster_backward expects cleared).  Issue
+ * it any time after list_capacity is known and before ps_raster_backward, on any stream; then
+ * set PS_FLAG_BWD_TEMP_ZEROED in the descriptor handed to ps_raster_backward. */
+int ps_raster_backward_prepare(const PsRasterDesc* desc, void* temp, size_t temp_bytes,
+                               size_t list_capacity, void* stream);
 
 /* Camera set-up for n_views views in one launch: everything render_cuda computes on the host
  * side before it calls the rasterizer (cuda_splatting.py:64-71 renorm by 1/near when

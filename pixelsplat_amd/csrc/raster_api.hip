@@ -59,7 +59,7 @@ void ps_raster_default_desc(PsRasterDesc* d) {
   if (!d) return;
   d->n_scenes = 1; d->views_per_scene = 1; d->n_gaussians = 0; d->height = 0; d->width = 0;
   d->sh_degree = 0; d->sh_coeffs = 0; d->sh_layout = PS_SH_GK3; d->cov_layout = PS_COV_6;
-  d->reserved = 0;
+  d->flags = 0;
   d->near_cull = 0.2f; d->guard = 1.3f; d->lowpass = 0.3f; d->w_eps = 1e-7f;
   d->lambda_floor = 0.1f; d->alpha_max = 0.99f; d->alpha_min = 1.0f / 255.0f;
   d->t_min = 1e-4f; d->det2_eps = 1e-7f;
@@ -147,27 +147,45 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   return check_launch();
 }
 
-int ps_raster_forward_render(const PsRasterDesc* d, const float* view_params, float* out_color,
-                             void* state, size_t state_bytes, void* temp, size_t temp_bytes,
-                             uint32_t* point_list, size_t list_capacity, void* stream) {
-  if (!desc_ok(d) || !view_params || !out_color || !state || !temp) return PS_ERR_BAD_ARG;
+int ps_raster_forward_bins(const PsRasterDesc* d, void* state, size_t state_bytes, void* temp,
+                           size_t temp_bytes, uint32_t* point_list, size_t list_capacity,
+                           void* stream) {
+  if (!desc_ok(d) || !state || !temp) return PS_ERR_BAD_ARG;
   if (!point_list && list_capacity > 0) return PS_ERR_BAD_ARG;
   if (int rc = check_sizes(*d, state_bytes, temp_bytes)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FwdPtrs p = fwd_ptrs(*d, state, temp);
   const uint32_t cap = clamp_capacity(list_capacity);
-  {
-    Scope sc(G_BINS, st);
-    launch_bin_write(*d, p.sorted_rect, p.sorted_idx, p.n_vis, p.bin_counts, p.tile_ranges,
-                     p.num_rendered, point_list, p.inv_slots, cap, st);
-  }
-  {
-    Scope sc(G_TILES_FWD, st);
-    launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list, cap, view_params,
-                         out_color,
-                         p.final_T, p.n_contrib, p.tile_end, st);
-  }
+  Scope sc(G_BINS, st);
+  launch_bin_write(*d, p.sorted_rect, p.sorted_idx, p.n_vis, p.bin_counts, p.tile_ranges,
+                   p.num_rendered, point_list, p.inv_slots, cap, st);
   return check_launch();
+}
+
+int ps_raster_forward_tiles(const PsRasterDesc* d, const float* view_params, float* out_color,
+                            void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                            const uint32_t* point_list, size_t list_capacity, void* stream) {
+  if (!desc_ok(d) || !view_params || !out_color || !state || !temp) return PS_ERR_BAD_ARG;
+  if (!point_list && list_capacity > 0) return PS_ERR_BAD_ARG;
+  if (int rc = check_sizes(*d, state_bytes, temp_bytes)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const FwdPtrs p = fwd_ptrs(*d, state, temp);
+  Scope sc(G_TILES_FWD, st);
+  launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list,
+                       clamp_capacity(list_capacity), view_params, out_color, p.final_T,
+                       p.n_contrib, p.tile_end, st);
+  return check_launch();
+}
+
+int ps_raster_forward_render(const PsRasterDesc* d, const float* view_params, float* out_color,
+                             void* state, size_t state_bytes, void* temp, size_t temp_bytes,
+                             uint32_t* point_list, size_t list_capacity, void* stream) {
+  if (!view_params || !out_color) return PS_ERR_BAD_ARG;
+  if (int rc = ps_raster_forward_bins(d, state, state_bytes, temp, temp_bytes, point_list,
+                                      list_capacity, stream))
+    return rc;
+  return ps_raster_forward_tiles(d, view_params, out_color, state, state_bytes, temp, temp_bytes,
+                                 point_list, list_capacity, stream);
 }
 
 int ps_raster_forward(const PsRasterDesc* d, const float* means, const float* cov,
@@ -214,7 +232,7 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   const uint32_t* tile_end = (const uint32_t*)(sb + L.tile_end);
   float* grad2d = (float*)(tb + T.grad2d);
   float* tile_grads = (float*)(tb + T.tile_grads);
-  {
+  if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
     Scope sc(G_MEMSET, st);
     // one memset covers grad2d (atomic path) and the per-(tile, entry) slots
     if (hipMemsetAsync(tb, 0, T.total, st) != hipSuccess) return PS_ERR_LAUNCH;
@@ -231,6 +249,16 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
                                dL_dcolors, dL_dopacity, dL_dmeans2D, st);
   }
   return check_launch();
+}
+
+int ps_raster_backward_prepare(const PsRasterDesc* d, void* temp, size_t temp_bytes,
+                               size_t list_capacity, void* stream) {
+  if (!desc_ok(d) || !temp) return PS_ERR_BAD_ARG;
+  const BwdTempLayout T = make_bwd_temp_layout(*d, clamp_capacity(list_capacity));
+  if (temp_bytes < T.total) return PS_ERR_WORKSPACE;
+  Scope sc(G_MEMSET, (hipStream_t)stream);
+  if (hipMemsetAsync(temp, 0, T.total, (hipStream_t)stream) != hipSuccess) return PS_ERR_LAUNCH;
+  return PS_OK;
 }
 
 int ps_camera_setup(int32_t n_views, const float* extrinsics, const float* intrinsics,

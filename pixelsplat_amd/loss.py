@@ -60,15 +60,25 @@ class _Mse(torch.autograd.Function):
         return grad * d_loss, None, None, None
 
 
-def mse_and_psnr(color: Tensor, target: Tensor, weight: float = 1.0):
-    """color, target [..., c, h, w] -> (weight * mean squared error, PSNR per image [...])."""
+def _mse(color: Tensor, target: Tensor, weight: float):
     _need_gpu(color, "LossMse")
     lead = color.shape[:-3]
     n_images = max(1, int(torch.Size(lead).numel()))
     pred = color.to(torch.float32).contiguous()
     tgt = target.to(torch.float32).expand_as(color).contiguous()
     loss, sse = _Mse.apply(pred, tgt, float(weight), n_images)
-    elems = pred.numel() // n_images
+    return loss, sse, lead, pred.numel() // n_images
+
+
+def mse_loss(color: Tensor, target: Tensor, weight: float = 1.0) -> Tensor:
+    """weight * mean((color - target)^2) (loss_mse.py:30-31) in one pass."""
+    return _mse(color, target, weight)[0]
+
+
+def mse_and_psnr(color: Tensor, target: Tensor, weight: float = 1.0):
+    """color, target [..., c, h, w] -> (weight * mean squared error, PSNR per image [...]),
+    both from the same pass."""
+    loss, sse, lead, elems = _mse(color, target, weight)
     return loss, (-10 * (sse[1] / elems).log10()).view(lead)
 
 
@@ -105,8 +115,7 @@ class LossMseCfgWrapper:
 
 class LossMse(Loss):
     def forward(self, prediction, batch, gaussians, global_step: int) -> Tensor:
-        loss, _ = mse_and_psnr(prediction.color, batch["target"]["image"], self.cfg.weight)
-        return loss
+        return mse_loss(prediction.color, batch["target"]["image"], self.cfg.weight)
 
 
 @dataclass
