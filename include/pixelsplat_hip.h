@@ -63,6 +63,10 @@ typedef enum PsStatus {
  * ps_raster_backward_prepare (e.g. on a second stream while the forward's tile kernels, which
  * are VALU-bound, run), so ps_raster_backward skips its own memset. */
 #define PS_FLAG_BWD_TEMP_ZEROED 1
+/* ps_raster_forward_plan leaves the SH -> RGB evaluation to a later ps_raster_forward_colors
+ * (any time before ps_raster_forward_tiles): a host that reads D back after the plan can queue
+ * it behind that copy, so the GPU evaluates colours while the host waits and allocates. */
+#define PS_FLAG_DEFER_SH_COLORS 2
 
 typedef struct PsRasterDesc {
   int32_t n_scenes;        /* S: independent Gaussian sets                           */
@@ -148,6 +152,9 @@ int ps_raster_forward_render(const PsRasterDesc* desc, const float* view_params,
 /* ps_raster_forward_render in its two halves (tile lists, then blending), for hosts that want
  * to put other work between them -- e.g. ps_raster_backward_prepare on a second stream once
  * the memory-bound list write is done, under the VALU-bound blend. */
+int ps_raster_forward_colors(const PsRasterDesc* desc, const float* means, const float* sh,
+                             const float* view_params, const int32_t* radii, void* state,
+                             size_t state_bytes, void* temp, size_t temp_bytes, void* stream);
 int ps_raster_forward_bins(const PsRasterDesc* desc, void* state, size_t state_bytes, void* temp,
                            size_t temp_bytes, uint32_t* point_list, size_t list_capacity,
                            void* stream);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libpixelsplat_hip.so")
 PS_SH_GK3, PS_SH_G3K = 0, 1
 PS_COV_6, PS_COV_33 = 0, 1
 PS_FLAG_BWD_TEMP_ZEROED = 1
+PS_FLAG_DEFER_SH_COLORS = 2
 PS_VIEW_STRIDE = 48
 PS_VIEW_VIEWMATRIX, PS_VIEW_PROJMATRIX, PS_VIEW_CAMPOS = 0, 16, 32
 PS_VIEW_TANFOVX, PS_VIEW_TANFOVY, PS_VIEW_BG, PS_VIEW_SCALE = 35, 36, 37, 40
@@ -65,7 +66,7 @@ EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
     "ps_raster_backward_temp_bytes",
     "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
-    "ps_raster_forward_render", "ps_raster_forward_bins", "ps_raster_forward_tiles", "ps_raster_backward", "ps_raster_backward_prepare",
+    "ps_raster_forward_render", "ps_raster_forward_colors", "ps_raster_forward_bins", "ps_raster_forward_tiles", "ps_raster_backward", "ps_raster_backward_prepare",
     "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
     "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
     "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_gaussian_adapter_views",
@@ -127,6 +128,9 @@ def load():
     lib.ps_raster_backward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [
         vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t] + [vp] * 6 + [vp]
     lib.ps_raster_backward.restype = C.c_int
+    lib.ps_raster_forward_colors.argtypes = [C.POINTER(PsRasterDesc), vp, vp, vp, vp, vp, C.c_size_t,
+                                             vp, C.c_size_t, vp]
+    lib.ps_raster_forward_colors.restype = C.c_int
     lib.ps_raster_forward_bins.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t, vp, C.c_size_t,
                                            vp, C.c_size_t, vp]
     lib.ps_raster_forward_bins.restype = C.c_int

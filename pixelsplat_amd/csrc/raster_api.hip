@@ -132,7 +132,8 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   {
     Scope sc(G_PRE_FWD, st);
     launch_preprocess_forward(*d, means, cov, sh, colors, opacity, view_params, p.records,
-                              p.keys_a, p.rects, out_radii, st);
+                              p.keys_a, p.rects, out_radii, true,
+                              !(d->flags & PS_FLAG_DEFER_SH_COLORS), st);
   }
   {
     Scope sc(G_SORT, st);
@@ -144,6 +145,21 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
     launch_bin_count(*d, p.sorted_rect, p.n_vis, p.bin_counts, p.tile_ranges, p.num_rendered,
                      p.tile_order, st);
   }
+  return check_launch();
+}
+
+int ps_raster_forward_colors(const PsRasterDesc* d, const float* means, const float* sh,
+                             const float* view_params, const int32_t* radii, void* state,
+                             size_t state_bytes, void* temp, size_t temp_bytes, void* stream) {
+  if (!desc_ok(d) || !means || !sh || !view_params || !radii || !state || !temp)
+    return PS_ERR_BAD_ARG;
+  if (d->sh_degree > 4) return PS_ERR_UNSUPPORTED;
+  if (int rc = check_sizes(*d, state_bytes, temp_bytes)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const FwdPtrs p = fwd_ptrs(*d, state, temp);
+  Scope sc(G_PRE_FWD, st);
+  launch_preprocess_forward(*d, means, nullptr, sh, nullptr, nullptr, view_params, p.records,
+                            p.keys_a, p.rects, const_cast<int32_t*>(radii), false, true, st);
   return check_launch();
 }
 

@@ -96,7 +96,8 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, hipStream_t st);
+                               uint2* rects, int32_t* radii, bool geometry, bool sh_colors,
+                               hipStream_t st);
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                  uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,

@@ -224,13 +224,14 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, hipStream_t st) {
-  {
+                               uint2* rects, int32_t* radii, bool geometry, bool sh_colors,
+                               hipStream_t st) {
+  if (geometry) {
     dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
     hipLaunchKernelGGL(geometry_forward_kernel, grid, block, 0, st, d, means, cov, colors,
                        opacity, view_params, records, keys, rects, radii);
   }
-  if (!sh) return;
+  if (!sh || !sh_colors) return;
   const int deg = d.sh_degree;
   // LDS staging needs an odd float stride per Gaussian (K = 1, 9, 25), at most 75
   const bool lds = ((d.sh_coeffs * 3) & 1) && d.sh_coeffs * 3 <= 75;

@@ -132,13 +132,26 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
         ev = torch.cuda.Event()
         ev.record()
         return ForwardResult(color, radii, state, plist, None, flag, ev, bwd_temp)
+    # exact sizing: D is read back once per batch.  The SH colours are deferred behind that
+    # copy, so the GPU evaluates them while the host waits for D, allocates and launches.
+    if sh is not None:
+        d.flags |= _lib.PS_FLAG_DEFER_SH_COLORS
     _lib.check(lib.ps_raster_forward_plan(
         C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
         _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _stream()),
         "ps_raster_forward_plan")
-    n = C.c_uint64(0)
-    _lib.check(lib.ps_raster_check(C.byref(d), _p(state), state.numel(), C.byref(n), _stream()),
-               "ps_raster_check")
+    lay = _lib.PsRasterStateLayout()
+    lib.ps_raster_state_layout(C.byref(d), C.byref(lay))
+    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+    host.copy_(state[lay.num_rendered:lay.num_rendered + 8].view(torch.int32), non_blocking=True)
+    copied = torch.cuda.Event()
+    copied.record()
+    if sh is not None:
+        _lib.check(lib.ps_raster_forward_colors(
+            C.byref(d), _p(means), _p(sh), _p(view_params), _p(radii), _p(state), state.numel(),
+            _p(temp), temp.numel(), _stream()), "ps_raster_forward_colors")
+    copied.synchronize()
+    n = C.c_uint64(int(host[0]) & 0xFFFFFFFF)
     plist = torch.empty(max(int(n.value), 1), dtype=torch.int32, device=dev)
     _lib.check(lib.ps_raster_forward_bins(
         C.byref(d), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist), int(n.value),
