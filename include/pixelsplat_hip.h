@@ -105,6 +105,7 @@ typedef struct PsRasterStateLayout {
   size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
   size_t tile_order;  /* uint32[V*T]: (view,tile) ids, longest list first (launch order)      */
   size_t inv_slots;   /* uint32[N][4]: point-list positions of a Gaussian touching <= 4 tiles  */
+  size_t clamp_bits;  /* uint8[N]: bit c set = SH colour channel c was clamped at 0 (visible entries) */
   size_t total;
 } PsRasterStateLayout;
 

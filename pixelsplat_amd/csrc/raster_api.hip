@@ -84,7 +84,7 @@ namespace {
 struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
   float* final_T; uint32_t* n_contrib; uint32_t* tile_end; uint32_t* tile_ranges;
-  uint32_t* num_rendered; uint32_t* tile_order; uint32_t* inv_slots;
+  uint32_t* num_rendered; uint32_t* tile_order; uint32_t* inv_slots; uint8_t* clamp_bits;
   uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *bin_counts;
 };
 FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
@@ -100,6 +100,7 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.num_rendered = (uint32_t*)(sb + L.num_rendered);
   p.tile_order = (uint32_t*)(sb + L.tile_order);
   p.inv_slots = (uint32_t*)(sb + L.inv_slots);
+  p.clamp_bits = (uint8_t*)(sb + L.clamp_bits);
   p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
   p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
   p.block_hist = (uint32_t*)(tb + T.block_hist); p.bin_counts = (uint32_t*)(tb + T.bin_counts);
@@ -132,7 +133,7 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   {
     Scope sc(G_PRE_FWD, st);
     launch_preprocess_forward(*d, means, cov, sh, colors, opacity, view_params, p.records,
-                              p.keys_a, p.rects, out_radii, true,
+                              p.keys_a, p.rects, out_radii, p.clamp_bits, true,
                               !(d->flags & PS_FLAG_DEFER_SH_COLORS), st);
   }
   {
@@ -159,7 +160,8 @@ int ps_raster_forward_colors(const PsRasterDesc* d, const float* means, const fl
   const FwdPtrs p = fwd_ptrs(*d, state, temp);
   Scope sc(G_PRE_FWD, st);
   launch_preprocess_forward(*d, means, nullptr, sh, nullptr, nullptr, view_params, p.records,
-                            p.keys_a, p.rects, const_cast<int32_t*>(radii), false, true, st);
+                            p.keys_a, p.rects, const_cast<int32_t*>(radii), p.clamp_bits, false,
+                            true, st);
   return check_launch();
 }
 
@@ -251,7 +253,7 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
     Scope sc(G_MEMSET, st);
     // one memset covers grad2d (atomic path) and the per-(tile, entry) slots
-    if (hipMemsetAsync(tb, 0, T.total, st) != hipSuccess) return PS_ERR_LAUNCH;
+    if (hipMemsetAsync(tb, 0, T.zeroed, st) != hipSuccess) return PS_ERR_LAUNCH;
   }
   {
     Scope sc(G_TILES_BWD, st);
@@ -261,7 +263,8 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   {
     Scope sc(G_PRE_BWD, st);
     launch_preprocess_backward(*d, means, cov, sh, view_params, records, radii, rects, inv_slots,
-                               tile_grads, capacity, grad2d, dL_dmeans, dL_dcov, dL_dsh,
+                               tile_grads, capacity, (const uint8_t*)(sb + L.clamp_bits),
+                               (float*)(tb + T.color_grads), grad2d, dL_dmeans, dL_dcov, dL_dsh,
                                dL_dcolors, dL_dopacity, dL_dmeans2D, st);
   }
   return check_launch();
@@ -273,7 +276,7 @@ int ps_raster_backward_prepare(const PsRasterDesc* d, void* temp, size_t temp_by
   const BwdTempLayout T = make_bwd_temp_layout(*d, clamp_capacity(list_capacity));
   if (temp_bytes < T.total) return PS_ERR_WORKSPACE;
   Scope sc(G_MEMSET, (hipStream_t)stream);
-  if (hipMemsetAsync(temp, 0, T.total, (hipStream_t)stream) != hipSuccess) return PS_ERR_LAUNCH;
+  if (hipMemsetAsync(temp, 0, T.zeroed, (hipStream_t)stream) != hipSuccess) return PS_ERR_LAUNCH;
   return PS_OK;
 }
 

@@ -25,7 +25,8 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
                          const int32_t* __restrict__ radii, const uint2* __restrict__ rects,
                          const uint32_t* __restrict__ inv_slots,
                          const float* __restrict__ tile_grads, uint32_t capacity,
-                         float* __restrict__ grad2d,
+                         const uint8_t* __restrict__ clamp_bits, float* __restrict__ color_grads,
+                         const float* __restrict__ grad2d,
                          float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov,
                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
                          float* __restrict__ dL_dmeans2D) {
@@ -84,9 +85,6 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
           gr[4] += a1[k].x; gr[5] += a1[k].y; gr[6] += a1[k].z; gr[7] += a1[k].w;
           gr[8] += a2[k];
         }
-        // the SH backward kernel reads the colour gradient from grad2d
-        float* go = grad2d + vg * kGradFloats;
-        go[6] = gr[6]; go[7] = gr[7]; go[8] = gr[8];
       } else {
         const float* gi = grad2d + vg * kGradFloats;
 #pragma unroll
@@ -106,6 +104,13 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
       o[2] = vis ? gr[8] : 0.f;
     }
     if (!vis) continue;
+    if (color_grads) {   // SH path: dL/dRGB with the forward's clamp applied, 12-byte rows
+      const uint32_t cb = clamp_bits[vg];
+      float* o = color_grads + vg * 3;
+      o[0] = (cb & 1u) ? 0.f : gr[6];
+      o[1] = (cb & 2u) ? 0.f : gr[7];
+      o[2] = (cb & 4u) ? 0.f : gr[8];
+    }
     const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
     const float* V = vp + PS_VIEW_VIEWMATRIX;
     const float* PV = vp + PS_VIEW_PROJMATRIX;
@@ -206,13 +211,15 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
 }
 
 // SH backward (runs after geometry_backward_kernel: it ADDS its dL/dmeans term).
+// 75 gradient accumulators + 25 basis values + 25 weights per lane: the kernel sits at the
+// 256-VGPR boundary (250 before the compact colour gradients, 258 after -- one wave per SIMD
+// instead of two, 479 -> 600 us); asking for three waves per SIMD makes the compiler settle at 242 VGPRs, no scratch (two waves)
 template <int DEG, bool LDS_SH>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3)))
 color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
                       const float* __restrict__ sh, const float* __restrict__ view_params,
-                      const float* __restrict__ records, const int32_t* __restrict__ radii,
-                      const float* __restrict__ grad2d, float* __restrict__ dL_dmeans,
-                      float* __restrict__ dL_dsh) {
+                      const int32_t* __restrict__ radii, const float* __restrict__ color_grads,
+                      float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
   const int G = d.n_gaussians, vps = d.views_per_scene, K = d.sh_coeffs;
   const int lane = threadIdx.x;
@@ -251,10 +258,8 @@ color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
     const float* vp = view_params + (size_t)v * PS_VIEW_STRIDE;
     const float scale = vp[PS_VIEW_SCALE];
     const float* cam = vp + PS_VIEW_CAMPOS;
-    const float* gr = grad2d + vg * kGradFloats;
-    const uint32_t clamp_bits = __float_as_uint(records[vg * kRecFloats + 11]);
-    const float gch[3] = {(clamp_bits & 1u) ? 0.f : gr[6], (clamp_bits & 2u) ? 0.f : gr[7],
-                          (clamp_bits & 4u) ? 0.f : gr[8]};
+    const float* gr = color_grads + vg * 3;   // clamp already applied (geometry backward)
+    const float gch[3] = {gr[0], gr[1], gr[2]};
     const float ox = m0x * scale - cam[0], oy = m0y * scale - cam[1], oz = m0z * scale - cam[2];
     const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox * inv, y = oy * inv, z = oz * inv;
@@ -319,13 +324,15 @@ void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,
                                 const uint32_t* inv_slots, const float* tile_grads,
-                                uint32_t capacity, float* grad2d, float* dL_dmeans,
+                                uint32_t capacity, const uint8_t* clamp_bits, float* color_grads,
+                                float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st) {
   {
     dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
     hipLaunchKernelGGL(geometry_backward_kernel, grid, block, 0, st, d, means, cov, view_params,
-                       radii, rects, inv_slots, tile_grads, capacity, grad2d, dL_dmeans, dL_dcov,
+                       radii, rects, inv_slots, tile_grads, capacity, clamp_bits,
+                       sh ? color_grads : (float*)nullptr, grad2d, dL_dmeans, dL_dcov,
                        sh ? (float*)nullptr : dL_dcolors, dL_dopacity, dL_dmeans2D);
   }
   if (!sh) return;
@@ -336,10 +343,10 @@ void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const
   do {                                                                                         \
     if (lds)                                                                                   \
       hipLaunchKernelGGL((color_backward_kernel<DEG, true>), grid, block, 0, st, d, means, sh, \
-                         view_params, records, radii, grad2d, dL_dmeans, dL_dsh);              \
+                         view_params, radii, color_grads, dL_dmeans, dL_dsh);                  \
     else                                                                                       \
       hipLaunchKernelGGL((color_backward_kernel<DEG, false>), grid, block, 0, st, d, means,    \
-                         sh, view_params, records, radii, grad2d, dL_dmeans, dL_dsh);          \
+                         sh, view_params, radii, color_grads, dL_dmeans, dL_dsh);              \
   } while (0)
   switch (deg) {
     case 0: PS_LAUNCH(0); break;

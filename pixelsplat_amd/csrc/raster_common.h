@@ -63,12 +63,17 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
   return t;
 }
 
-struct BwdTempLayout { size_t grad2d, tile_grads, total; };
+// grad2d and tile_grads are accumulators (zeroed: bytes [0, zeroed)); color_grads is the compact
+// per-(view, Gaussian) dL/dRGB the geometry backward hands to the SH backward (12 B rows
+// instead of 3 floats out of every 36-byte grad2d row and 1 out of every 48-byte record)
+struct BwdTempLayout { size_t grad2d, tile_grads, zeroed, color_grads, total; };
 inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_capacity) {
   const Dims m = make_dims(d);
   BwdTempLayout t; size_t o = 0;
   t.grad2d = o; o = align_up(o + m.N * kGradFloats * 4);
   t.tile_grads = o; o = align_up(o + list_capacity * kSlotFloats * 4);
+  t.zeroed = o;
+  t.color_grads = o; o = align_up(o + m.N * 3 * 4);
   t.total = o;
   return t;
 }
@@ -88,6 +93,7 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.num_rendered = o; o = align_up(o + 8);
   s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
   s.inv_slots = o; o = align_up(o + m.N * kInvSlots * 4);
+  s.clamp_bits = o; o = align_up(o + m.N);
   s.total = o;
   return s;
 }
@@ -96,8 +102,8 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, bool geometry, bool sh_colors,
-                               hipStream_t st);
+                               uint2* rects, int32_t* radii, uint8_t* clamp_bits, bool geometry,
+                               bool sh_colors, hipStream_t st);
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                  uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
@@ -130,7 +136,8 @@ void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,
                                 const uint32_t* inv_slots, const float* tile_grads,
-                                uint32_t capacity, float* grad2d, float* dL_dmeans,
+                                uint32_t capacity, const uint8_t* clamp_bits, float* color_grads,
+                                float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st);
 

@@ -156,7 +156,8 @@ template <int DEG, bool LDS_SH>
 __global__ void __launch_bounds__(kWave, LDS_SH ? 4 : 1)
 color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
                      const float* __restrict__ sh, const float* __restrict__ view_params,
-                     const int32_t* __restrict__ radii, float* __restrict__ records) {
+                     const int32_t* __restrict__ radii, float* __restrict__ records,
+                     uint8_t* __restrict__ clamp_out) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
   constexpr int GPW = LDS_SH ? 32 : kWave;          // Gaussians per wave
   const int G = d.n_gaussians, vps = d.views_per_scene, K = d.sh_coeffs;
@@ -218,14 +219,15 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
     }
     float4* r = reinterpret_cast<float4*>(records + ((size_t)v * G + g) * kRecFloats);
     r[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
+    clamp_out[(size_t)v * G + g] = (uint8_t)clamp_bits;   // compact copy for the backward
   }
 }
 
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, bool geometry, bool sh_colors,
-                               hipStream_t st) {
+                               uint2* rects, int32_t* radii, uint8_t* clamp_bits, bool geometry,
+                               bool sh_colors, hipStream_t st) {
   if (geometry) {
     dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
     hipLaunchKernelGGL(geometry_forward_kernel, grid, block, 0, st, d, means, cov, colors,
@@ -241,10 +243,10 @@ void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const 
   do {                                                                                        \
     if (lds)                                                                                  \
       hipLaunchKernelGGL((color_forward_kernel<DEG, true>), grid32, block, 0, st, d, means,   \
-                         sh, view_params, radii, records);                                    \
+                         sh, view_params, radii, records, clamp_bits);                        \
     else                                                                                      \
       hipLaunchKernelGGL((color_forward_kernel<DEG, false>), grid, block, 0, st, d, means,    \
-                         sh, view_params, radii, records);                                    \
+                         sh, view_params, radii, records, clamp_bits);                        \
   } while (0)
   switch (deg) {
     case 0: PS_LAUNCH(0); break;

@@ -119,11 +119,17 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
     temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
     if cfg.list_capacity > 0:
         plist = torch.empty(cfg.list_capacity, dtype=torch.int32, device=dev)
-        bwd_temp = _zeroed_backward_temp(cfg, plist.numel(), dev) if want_backward else None
-        _lib.check(lib.ps_raster_forward(
+        _lib.check(lib.ps_raster_forward_plan(
             C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
-            _p(color), _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist),
-            plist.numel(), _stream()), "ps_raster_forward")
+            _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _stream()),
+            "ps_raster_forward_plan")
+        _lib.check(lib.ps_raster_forward_bins(
+            C.byref(d), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist), plist.numel(),
+            _stream()), "ps_raster_forward_bins")
+        bwd_temp = _zeroed_backward_temp(cfg, plist.numel(), dev) if want_backward else None
+        _lib.check(lib.ps_raster_forward_tiles(
+            C.byref(d), _p(view_params), _p(color), _p(state), state.numel(), _p(temp),
+            temp.numel(), _p(plist), plist.numel(), _stream()), "ps_raster_forward_tiles")
         lay = _lib.PsRasterStateLayout()
         lib.ps_raster_state_layout(C.byref(d), C.byref(lay))
         flag = torch.empty(2, dtype=torch.int32, pin_memory=True)  # caching host allocator
@@ -134,7 +140,8 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
         return ForwardResult(color, radii, state, plist, None, flag, ev, bwd_temp)
     # exact sizing: D is read back once per batch.  The SH colours are deferred behind that
     # copy, so the GPU evaluates them while the host waits for D, allocates and launches.
-    if sh is not None:
+    _defer = sh is not None
+    if _defer:
         d.flags |= _lib.PS_FLAG_DEFER_SH_COLORS
     _lib.check(lib.ps_raster_forward_plan(
         C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
@@ -146,7 +153,7 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
     host.copy_(state[lay.num_rendered:lay.num_rendered + 8].view(torch.int32), non_blocking=True)
     copied = torch.cuda.Event()
     copied.record()
-    if sh is not None:
+    if _defer:
         _lib.check(lib.ps_raster_forward_colors(
             C.byref(d), _p(means), _p(sh), _p(view_params), _p(radii), _p(state), state.numel(),
             _p(temp), temp.numel(), _stream()), "ps_raster_forward_colors")
