@@ -275,7 +275,7 @@ int ps_raster_backward_prepare(const PsRasterDesc* d, void* temp, size_t temp_by
   if (!desc_ok(d) || !temp) return PS_ERR_BAD_ARG;
   const BwdTempLayout T = make_bwd_temp_layout(*d, clamp_capacity(list_capacity));
   if (temp_bytes < T.total) return PS_ERR_WORKSPACE;
-  Scope sc(G_MEMSET, (hipStream_t)stream);
+  // not timed as a profile group: it is meant to run concurrently with other work
   if (hipMemsetAsync(temp, 0, T.zeroed, (hipStream_t)stream) != hipSuccess) return PS_ERR_LAUNCH;
   return PS_OK;
 }
