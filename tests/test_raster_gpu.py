@@ -266,3 +266,57 @@ def test_camera_setup_matches_reference_host_math(gpu_device):
     assert torch.allclose(vp[:, 32:35], campos, rtol=1e-6, atol=1e-7)
     assert torch.allclose(vp[:, 35:37], tanfov, rtol=1e-5)
     assert torch.allclose(vp[:, 37:40], bg) and torch.allclose(vp[:, 40], scale)
+
+
+def test_one_call_abi_equals_the_split_calls(gpu_device):
+    """ps_raster_forward (plan + render in one call, in-line memset in the backward) against the
+    host path's plan / deferred colours / bins / side-stream memset / tiles sequence, and the
+    fixed-capacity mode against exact sizing: identical bits for images, radii and gradients
+    of the slot (deterministic) path."""
+    import ctypes as C
+
+    from pixelsplat_amd import _lib
+    from pixelsplat_amd.raster import RasterConfig, _p, _stream, rasterize
+    from pixelsplat_amd.decoder import camera_setup
+
+    dev = gpu_device
+    ctx, tgt, g, target = make_workload(1, (64, 64), v_ctx=2, v_tgt=3, seed=4)
+    V = 3
+    means = g.means.to(dev).contiguous()
+    cov = g.covariances.to(dev).contiguous()
+    sh = g.harmonics.to(dev).contiguous()
+    op = g.opacities.to(dev).contiguous()
+    vp = camera_setup(tgt.extrinsics.reshape(V, 4, 4).to(dev), tgt.intrinsics.reshape(V, 3, 3).to(dev),
+                      tgt.near.reshape(V).to(dev), tgt.far.reshape(V).to(dev),
+                      torch.zeros(V, 3, device=dev))
+    k = sh.shape[-1]
+    cfg = RasterConfig(n_scenes=1, views_per_scene=V, n_gaussians=means.shape[1], height=64, width=64,
+                       sh_degree=int(round(k ** 0.5)) - 1, sh_coeffs=k, sh_layout=_lib.PS_SH_G3K,
+                       cov_layout=_lib.PS_COV_33)
+
+    def run(c):
+        leaves = [t.clone().requires_grad_(True) for t in (means, cov, op, sh)]
+        img, radii = rasterize(c, leaves[0], leaves[1], leaves[2], vp, sh=leaves[3])
+        (img * torch.linspace(0.5, 1.5, img.numel(), device=dev).view_as(img)).sum().backward()
+        return img.detach(), radii, [t.grad for t in leaves]
+
+    img_a, radii_a, grads_a = run(cfg)
+    import dataclasses
+    img_b, radii_b, grads_b = run(dataclasses.replace(cfg, list_capacity=200000))
+    assert torch.equal(img_a, img_b) and torch.equal(radii_a, radii_b)
+    for ga, gb in zip(grads_a, grads_b):
+        torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-7)   # atomics for large Gaussians
+
+    # the single-call ABI
+    lib = _lib.load()
+    d = cfg.desc()
+    color = torch.empty((V, 3, 64, 64), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, means.shape[1]), dtype=torch.int32, device=dev)
+    state = torch.empty(lib.ps_raster_state_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    plist = torch.empty(200000, dtype=torch.int32, device=dev)
+    _lib.check(lib.ps_raster_forward(C.byref(d), _p(means), _p(cov), _p(sh), None, _p(op), _p(vp),
+                                     _p(color), _p(radii), _p(state), state.numel(), _p(temp),
+                                     temp.numel(), _p(plist), plist.numel(), _stream()),
+               "ps_raster_forward")
+    assert torch.equal(color, img_a) and torch.equal(radii, radii_a)
