@@ -164,13 +164,15 @@ def main():
     rank, world, local = P.init_from_env()
     dev = torch.device("cuda", local)
 
-    from pixelsplat_amd import _lib
+    from pixelsplat_amd import _lib, gemm_tuning
     from pixelsplat_amd.decoder import render_cuda
     from pixelsplat_amd.loss import mse_loss
     from pixelsplat_amd.raster import export_bins
     from pixelsplat_amd.synthetic import make_workload
 
     lib = _lib.load()  # raises if the HIP library is missing: no fallback
+    # library GEMMs: committed TunableOp table, look-up only (pixelsplat_amd/gemm_tuning)
+    tuned_gemms = (not os.environ.get("PIXELSPLAT_NO_TUNED_GEMMS")) and gemm_tuning.enable()
     hw = (args.size, args.size)
     b, v = args.batch, args.views
     ctx, tgt, g, target = make_workload(b, hw, v_ctx=2, v_tgt=v, seed=P.rank_seed(0, rank))
@@ -397,6 +399,8 @@ def main():
                 "valu_issue_frac": (round(valu_ms / dom_ms, 3) if valu_ms else None),
                 "algorithmic_bytes_per_launch": alg[dom],
             },
+            "library_gemm_table": ("pixelsplat_amd/gemm_tuning/gfx950_rocm7_torch2.10.csv"
+                                   if tuned_gemms else None),
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},
             "kernel_launches_per_step": {k: groups[k][1] / args.steps for k in groups},
             "paths": {

@@ -92,3 +92,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_graft_entry_build():
     import __graft_entry__ as ge
     ge.build()
+
+
+def test_gemm_tuning_table_is_well_formed_and_inert_without_a_gpu():
+    """The committed TunableOp table for the library GEMMs: validators + one row per shape;
+    enable() is a no-op (False) where there is no GPU."""
+    import csv
+
+    from pixelsplat_amd import gemm_tuning
+
+    rows = list(csv.reader(open(gemm_tuning.TABLE)))
+    validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert {"PT_VERSION", "HIP_VERSION", "GCN_ARCH_NAME"} <= set(validators)
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950")
+    entries = [r for r in rows if r[0] != "Validator"]
+    assert entries and all(len(r) == 4 and float(r[3]) > 0 for r in entries)
+    import torch
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() is False
