@@ -29,7 +29,8 @@ def enable(path: str | None = None) -> bool:
         tun.write_file_on_exit(False)
     else:   # this build always writes its table at exit: send that to the temp directory
         import tempfile
-        tun.set_filename(os.path.join(tempfile.gettempdir(), "pixelsplat_tunableop.csv"))
+        tun.set_filename(os.path.join(tempfile.gettempdir(),
+                                      f"pixelsplat_tunableop_{os.getpid()}.csv"))
     try:
         return bool(tun.read_file(path or TABLE))
     except Exception:   # malformed / foreign table: keep the defaults
