@@ -46,16 +46,25 @@ def parse():
     return p.parse_args()
 
 
+# profile groups that are ONE kernel (their event time is that kernel's duration)
+SINGLE_KERNEL_GROUPS = {
+    "tiles_backward": "tiles_backward_kernel", "tiles_forward": "tiles_forward_kernel",
+    "epipolar_attention_forward": "epipolar_attn_forward_kernel",
+    "epipolar_attention_backward": "epipolar_attn_backward_kernel",
+    "epipolar_feature_grad": "epipolar_dfmap_kernel",
+    "gaussian_adapter_backward": "adapter_backward_kernel<4, 0>",
+    "depth_sampler_forward": "depth_sampler_forward_kernel",
+    "depth_sampler_backward": "depth_sampler_backward_kernel",
+}
+
+
 def pmc_traffic(group):
     """HBM-side bytes per launch of the kernel behind a profile group, from the committed
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (tools/pmc_summary.py; counters cannot be
     read from inside the process).  None when no summary is committed or the group is not a
     single kernel."""
     import glob
-    key = {"tiles_backward": "tiles_backward_kernel", "tiles_forward": "tiles_forward_kernel",
-           "epipolar_attention_forward": "epipolar_attn_forward_kernel",
-           "epipolar_attention_backward": "epipolar_attn_backward_kernel",
-           "epipolar_feature_grad": "epipolar_dfmap_kernel"}.get(group)
+    key = SINGLE_KERNEL_GROUPS.get(group)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if key is None or not files:
         return None, None
@@ -71,10 +80,7 @@ def pmc_valu_busy_ms(group):
     """VALU-issue time per launch (SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs at 2.4 GHz) of
     the kernel behind a profile group, from the committed PMC summary (tools/pmc_sq_summary.py)."""
     import glob
-    key = {"tiles_backward": "tiles_backward_kernel", "tiles_forward": "tiles_forward_kernel",
-           "epipolar_attention_forward": "epipolar_attn_forward_kernel",
-           "epipolar_attention_backward": "epipolar_attn_backward_kernel",
-           "epipolar_feature_grad": "epipolar_dfmap_kernel"}.get(group)
+    key = SINGLE_KERNEL_GROUPS.get(group)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq.json")))
     if key is None or not files:
         return None
@@ -399,6 +405,16 @@ def main():
                 "valu_issue_frac": (round(valu_ms / dom_ms, 3) if valu_ms else None),
                 "algorithmic_bytes_per_launch": alg[dom],
             },
+            # every single-kernel group: live duration x committed PMC traffic (HBM-side bytes per
+            # launch) -> achieved GB/s, and the VALU-issue share where the PMC run has it
+            "kernel_rooflines": {
+                g_: {"ms": round(groups[g_][0], 4),
+                     "hbm_gb_per_s": round(pmc_traffic(g_)[0] / (groups[g_][0] * 1e-3) / 1e9, 1),
+                     "hbm_frac": round(pmc_traffic(g_)[0] / (groups[g_][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                     "valu_issue_frac": (round(pmc_valu_busy_ms(g_) / groups[g_][0], 3)
+                                         if pmc_valu_busy_ms(g_) else None)}
+                for g_ in SINGLE_KERNEL_GROUPS
+                if g_ in groups and groups[g_][0] > 0 and pmc_traffic(g_)[0]},
             "library_gemm_table": ("pixelsplat_amd/gemm_tuning/gfx950_rocm7_torch2.10.csv"
                                    if tuned_gemms else None),
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},

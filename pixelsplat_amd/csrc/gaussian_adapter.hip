@@ -260,32 +260,34 @@ adapter_forward_kernel(AdapterDims dm, float smin, float smax, float eps,
 #pragma unroll
       for (int a = 0; a < 3; ++a) o[9 + a] = fmaf(g.dirw[a], depth, vw[kViewOrigin + a]);
     }
-    // SH: mask, then the block-diagonal Wigner-D of this view, in place in the slab
+  }
+  // SH: mask, then the block-diagonal Wigner-D of this view, in place in the slab.  Lane =
+  // (entry, colour channel): 3 x kEntries lanes work here instead of kEntries (the per-entry
+  // geometry above runs on 16 lanes; these 165 FMAs per channel were 55 % of the kernel's
+  // VALU time when one lane did all three channels)
+  if (lane < 3 * kEntries && (lane % kEntries) < rows) {
+    const int c = lane / kEntries;
+    float* sh = rawS + (lane % kEntries) * CIN + SKIP + 7 + c * K;
     const float* D = vw + kViewD;
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-      float* sh = mine + 7 + c * K;
-      float in[K], out[K];
+    float in[K], out[K];
 #pragma unroll
-      for (int j = 0; j < K; ++j) in[j] = sh[j];
-      out[0] = in[0];
+    for (int j = 0; j < K; ++j) in[j] = sh[j];
+    out[0] = in[0];
 #pragma unroll
-      for (int l = 1; l <= DEG; ++l) {
-        constexpr int dummy = 0; (void)dummy;
-        const int n = 2 * l + 1, b0 = l * l;
-        const float* Dl = D + wigner_block(l);
-        const float mk = sh_mask_of(l);
+    for (int l = 1; l <= DEG; ++l) {
+      const int n = 2 * l + 1, b0 = l * l;
+      const float* Dl = D + wigner_block(l);
+      const float mk = sh_mask_of(l);
 #pragma unroll
-        for (int i = 0; i < n; ++i) {
-          float acc = 0.f;
+      for (int i = 0; i < n; ++i) {
+        float acc = 0.f;
 #pragma unroll
-          for (int j = 0; j < n; ++j) acc = fmaf(Dl[i * n + j], in[b0 + j], acc);
-          out[b0 + i] = acc * mk;
-        }
+        for (int j = 0; j < n; ++j) acc = fmaf(Dl[i * n + j], in[b0 + j], acc);
+        out[b0 + i] = acc * mk;
       }
-#pragma unroll
-      for (int j = 0; j < K; ++j) sh[j] = out[j];
     }
+#pragma unroll
+    for (int j = 0; j < K; ++j) sh[j] = out[j];
   }
   wave_lds_sync();
 
@@ -468,31 +470,31 @@ adapter_backward_kernel(AdapterDims dm, float smin, float smax, float eps,
     } else {
       *reinterpret_cast<float2*>(d_coords + 2 * (e0 + lane)) = make_float2(dcx, dcy);
     }
-    // SH: D^T and the mask, in place
+  }
+  // SH: D^T and the mask, in place; lane = (entry, colour channel) as in the forward
+  if (lane < 3 * kEntries && (lane % kEntries) < rows) {
+    const int c = lane / kEntries;
+    float* sh = outS + (lane % kEntries) * CIN + SKIP + 7 + c * K;
     const float* D = vw + kViewD;
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-      float* sh = mine + 7 + c * K;
-      float in[K], out[K];
+    float in[K], out[K];
 #pragma unroll
-      for (int j = 0; j < K; ++j) in[j] = sh[j];
-      out[0] = in[0];
+    for (int j = 0; j < K; ++j) in[j] = sh[j];
+    out[0] = in[0];
 #pragma unroll
-      for (int l = 1; l <= DEG; ++l) {
-        const int n = 2 * l + 1, b0 = l * l;
-        const float* Dl = D + wigner_block(l);
-        const float mk = sh_mask_of(l);
+    for (int l = 1; l <= DEG; ++l) {
+      const int n = 2 * l + 1, b0 = l * l;
+      const float* Dl = D + wigner_block(l);
+      const float mk = sh_mask_of(l);
 #pragma unroll
-        for (int j = 0; j < n; ++j) {
-          float acc = 0.f;
+      for (int j = 0; j < n; ++j) {
+        float acc = 0.f;
 #pragma unroll
-          for (int i = 0; i < n; ++i) acc = fmaf(Dl[i * n + j], in[b0 + i], acc);
-          out[b0 + j] = acc * mk;
-        }
+        for (int i = 0; i < n; ++i) acc = fmaf(Dl[i * n + j], in[b0 + i], acc);
+        out[b0 + j] = acc * mk;
       }
-#pragma unroll
-      for (int j = 0; j < K; ++j) sh[j] = out[j];
     }
+#pragma unroll
+    for (int j = 0; j < K; ++j) sh[j] = out[j];
   }
   wave_lds_sync();
   float* dst = d_raw + e0 * CIN;
