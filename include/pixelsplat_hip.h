@@ -93,7 +93,7 @@ typedef struct PsRasterDesc {
 /* byte offsets of the arrays inside the `state` buffer (for tests / debugging).
  * V = n_scenes*views_per_scene, N = V*G, P = H*W, T = tiles per view. */
 typedef struct PsRasterStateLayout {
-  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,depth,tiles touched(i32) | r,g,b,clamp bits */
+  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,depth,packed small-rect origin (u32) | r,g,b,clamp bits */
   size_t rects;       /* uint16[N][4]: tile rect xmin,ymin,xmax,ymax                   */
   size_t sorted_idx;  /* uint32[N]: per view, Gaussian ids in (depth, id) order; first n_vis valid */
   size_t sorted_rect; /* uint16[N][4]: rects permuted into sorted order                */
@@ -104,7 +104,6 @@ typedef struct PsRasterStateLayout {
   size_t tile_ranges; /* uint32[V][T][2]: (start, count) of the tile's list in point_list     */
   size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
   size_t tile_order;  /* uint32[V*T]: (view,tile) ids, longest list first (launch order)      */
-  size_t inv_slots;   /* uint32[N][4]: point-list positions of a Gaussian touching <= 4 tiles  */
   size_t clamp_bits;  /* uint8[N]: bit c set = SH colour channel c was clamped at 0 (visible entries) */
   size_t total;
 } PsRasterStateLayout;

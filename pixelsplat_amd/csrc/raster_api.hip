@@ -84,7 +84,7 @@ namespace {
 struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
   float* final_T; uint32_t* n_contrib; uint32_t* tile_end; uint32_t* tile_ranges;
-  uint32_t* num_rendered; uint32_t* tile_order; uint32_t* inv_slots; uint8_t* clamp_bits;
+  uint32_t* num_rendered; uint32_t* tile_order; uint8_t* clamp_bits;
   uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *bin_counts;
 };
 FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
@@ -99,7 +99,6 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.tile_ranges = (uint32_t*)(sb + L.tile_ranges);
   p.num_rendered = (uint32_t*)(sb + L.num_rendered);
   p.tile_order = (uint32_t*)(sb + L.tile_order);
-  p.inv_slots = (uint32_t*)(sb + L.inv_slots);
   p.clamp_bits = (uint8_t*)(sb + L.clamp_bits);
   p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
   p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
@@ -176,7 +175,7 @@ int ps_raster_forward_bins(const PsRasterDesc* d, void* state, size_t state_byte
   const uint32_t cap = clamp_capacity(list_capacity);
   Scope sc(G_BINS, st);
   launch_bin_write(*d, p.sorted_rect, p.sorted_idx, p.n_vis, p.bin_counts, p.tile_ranges,
-                   p.num_rendered, point_list, p.inv_slots, cap, st);
+                   p.num_rendered, point_list, cap, st);
   return check_launch();
 }
 
@@ -244,7 +243,6 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   const uint2* rects = (const uint2*)(sb + L.rects);
   const uint32_t* tile_ranges = (const uint32_t*)(sb + L.tile_ranges);
   const uint32_t* tile_order = (const uint32_t*)(sb + L.tile_order);
-  const uint32_t* inv_slots = (const uint32_t*)(sb + L.inv_slots);
   const float* final_T = (const float*)(sb + L.final_T);
   const uint32_t* n_contrib = (const uint32_t*)(sb + L.n_contrib);
   const uint32_t* tile_end = (const uint32_t*)(sb + L.tile_end);
@@ -262,8 +260,8 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   }
   {
     Scope sc(G_PRE_BWD, st);
-    launch_preprocess_backward(*d, means, cov, sh, view_params, records, radii, rects, inv_slots,
-                               tile_grads, capacity, (const uint8_t*)(sb + L.clamp_bits),
+    launch_preprocess_backward(*d, means, cov, sh, view_params, records, radii, rects,
+                               tile_grads, (const uint8_t*)(sb + L.clamp_bits),
                                (float*)(tb + T.color_grads), grad2d, dL_dmeans, dL_dcov, dL_dsh,
                                dL_dcolors, dL_dopacity, dL_dmeans2D, st);
   }

@@ -23,8 +23,7 @@ __global__ void __launch_bounds__(256)
 geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
                          const float* __restrict__ cov, const float* __restrict__ view_params,
                          const int32_t* __restrict__ radii, const uint2* __restrict__ rects,
-                         const uint32_t* __restrict__ inv_slots,
-                         const float* __restrict__ tile_grads, uint32_t capacity,
+                         const float* __restrict__ tile_grads,
                          const uint8_t* __restrict__ clamp_bits, float* __restrict__ color_grads,
                          const float* __restrict__ grad2d,
                          float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov,
@@ -59,21 +58,20 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
 #pragma unroll
     for (int c = 0; c < kGradFloats; ++c) gr[c] = 0.f;
     if (vis) {
-      // Gaussians touching <= 4 tiles: sum their private (tile, entry) slots in tile order
+      // Gaussians touching <= 4 tiles: sum their private (Gaussian, tile) slots in tile order
       // (deterministic); larger ones were accumulated with atomics into grad2d
       const uint2 r = rects[vg];
       const uint32_t area = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
-      if (area <= (uint32_t)kInvSlots) {
-        // all slot loads are issued before the first add (one index load + up to 4 slots in
-        // flight instead of a chain of 8 dependent latencies); the sum keeps the tile order
-        const uint4 iv = *reinterpret_cast<const uint4*>(inv_slots + vg * kInvSlots);
-        const uint32_t posk[kInvSlots] = {iv.x, iv.y, iv.z, iv.w};
+      if (area <= (uint32_t)kInvSlots && (H + kTile - 1) / kTile <= 16383) {
+        // its private slots (one per tile of the rect, row-major; the tile backward wrote every
+        // one of them): all loads are issued before the first add, the sum keeps the tile order
         float4 a0[kInvSlots], a1[kInvSlots];
         float a2[kInvSlots];
+        const float* sp0 = tile_grads + vg * (size_t)(kInvSlots * kSlotFloats);
 #pragma unroll
         for (int k = 0; k < kInvSlots; ++k) {
-          const bool on = (uint32_t)k < area && posk[k] < capacity;
-          const float* sp = tile_grads + (size_t)(on ? posk[k] : 0u) * kSlotFloats;
+          const bool on = (uint32_t)k < area;
+          const float* sp = sp0 + (on ? k : 0) * kSlotFloats;
           const float4* tg = reinterpret_cast<const float4*>(sp);
           a0[k] = on ? tg[0] : make_float4(0.f, 0.f, 0.f, 0.f);
           a1[k] = on ? tg[1] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -323,15 +321,15 @@ color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,
-                                const uint32_t* inv_slots, const float* tile_grads,
-                                uint32_t capacity, const uint8_t* clamp_bits, float* color_grads,
+                                const float* tile_grads, const uint8_t* clamp_bits,
+                                float* color_grads,
                                 float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st) {
   {
     dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
     hipLaunchKernelGGL(geometry_backward_kernel, grid, block, 0, st, d, means, cov, view_params,
-                       radii, rects, inv_slots, tile_grads, capacity, clamp_bits,
+                       radii, rects, tile_grads, clamp_bits,
                        sh ? color_grads : (float*)nullptr, grad2d, dL_dmeans, dL_dcov,
                        sh ? (float*)nullptr : dL_dcolors, dL_dopacity, dL_dmeans2D);
   }

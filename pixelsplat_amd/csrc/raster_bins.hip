@@ -21,8 +21,7 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
            const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ n_vis,
            uint32_t* __restrict__ counts /*[V][nb][tiles]: count, then block offset*/,
            const uint32_t* __restrict__ tile_ranges /*[V][tiles][2]*/,
-           uint32_t* __restrict__ point_list, uint32_t* __restrict__ inv_slots,
-           uint32_t capacity) {
+           uint32_t* __restrict__ point_list, uint32_t capacity) {
   __shared__ uint2 s_rect[kBinChunk];
   __shared__ uint32_t s_idx[WRITE ? kBinChunk : 1];
   const Dims m = make_dims(d);
@@ -70,13 +69,6 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
             ++k;
           } else {
             if (off < capacity) point_list[off] = s_idx[i];
-            // inverse map for Gaussians touching <= 4 tiles: where each of its tiles keeps it
-            const uint32_t wr = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
-            const uint32_t hr = (r.y >> 16) - (r.x >> 16);
-            if (wr * hr <= (uint32_t)kInvSlots) {
-              const uint32_t kk = ((Tt >> 16) - (r.x >> 16)) * wr + ((Tt & 0xFFFFu) - (r.x & 0xFFFFu));
-              inv_slots[(vo + s_idx[i]) * kInvSlots + kk] = off;
-            }
             ++off;
           }
         }
@@ -241,7 +233,7 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
   else
     hipLaunchKernelGGL(bin_kernel<false>, grid, dim3(256), 0, st, d, sorted_rect,
                        (const uint32_t*)nullptr, n_vis, counts, (const uint32_t*)nullptr,
-                       (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                       (uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3((m.V * m.tiles + 255) / 256), dim3(256), 0, st,
                      d, n_vis, counts, tile_ranges);
   hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, d, tile_ranges,
@@ -250,13 +242,13 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
 
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
                       const uint32_t* n_vis, uint32_t* counts, const uint32_t* tile_ranges,
-                      uint32_t* num_rendered, uint32_t* point_list, uint32_t* inv_slots,
-                      uint32_t capacity, hipStream_t st) {
+                      uint32_t* num_rendered, uint32_t* point_list, uint32_t capacity,
+                      hipStream_t st) {
   const Dims m = make_dims(d);
   dim3 grid(m.nbin, m.V);
   hipLaunchKernelGGL(bin_flag_kernel, dim3(1), dim3(64), 0, st, num_rendered, capacity);
   hipLaunchKernelGGL(bin_kernel<true>, grid, dim3(256), 0, st, d, sorted_rect, sorted_idx, n_vis,
-                     counts, tile_ranges, point_list, inv_slots, capacity);
+                     counts, tile_ranges, point_list, capacity);
 }
 
 }  // namespace ps

@@ -15,6 +15,9 @@ constexpr int kRecFloats = 12;          // one 48-byte record per (view, gaussia
 constexpr int kGradFloats = 9;          // dxy(2) dconic(3) dopacity(1) drgb(3)
 constexpr int kSlotFloats = 12;         // per-(tile, entry) gradient slot: 9 used, 48-byte aligned
 constexpr int kInvSlots = 4;            // Gaussians touching <= 4 tiles use slots, larger ones atomics
+// records[7] of a Gaussian touching <= kInvSlots tiles: bit 31 | (rect width - 1) << 29 |
+// ymin << 15 | xmin (tile units); 0 for larger rects (and for tile grids over 16383 rows)
+constexpr uint32_t kSmallFlag = 0x80000000u;
 
 // sort geometry
 constexpr int kSortThreads = 256;
@@ -71,8 +74,11 @@ inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_cap
   const Dims m = make_dims(d);
   BwdTempLayout t; size_t o = 0;
   t.grad2d = o; o = align_up(o + m.N * kGradFloats * 4);
-  t.tile_grads = o; o = align_up(o + list_capacity * kSlotFloats * 4);
-  t.zeroed = o;
+  t.zeroed = o;   // only the atomic accumulators need clearing
+  // one private slot per (view, Gaussian, tile of its <= 4-tile rect): every one is written
+  // exactly once by the tile backward (values or zeros), so no memset and no position map
+  (void)list_capacity;
+  t.tile_grads = o; o = align_up(o + m.N * kInvSlots * kSlotFloats * 4);
   t.color_grads = o; o = align_up(o + m.N * 3 * 4);
   t.total = o;
   return t;
@@ -92,7 +98,6 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.tile_ranges = o; o = align_up(o + (size_t)m.V * m.tiles * 8);
   s.num_rendered = o; o = align_up(o + 8);
   s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
-  s.inv_slots = o; o = align_up(o + m.N * kInvSlots * 4);
   s.clamp_bits = o; o = align_up(o + m.N);
   s.total = o;
   return s;
@@ -114,7 +119,7 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
                       uint32_t* tile_order, hipStream_t st);
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
                       const uint32_t* n_vis, uint32_t* counts, const uint32_t* tile_ranges,
-                      uint32_t* num_rendered, uint32_t* point_list, uint32_t* inv_slots,
+                      uint32_t* num_rendered, uint32_t* point_list,
                       uint32_t capacity, hipStream_t st);
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
@@ -135,8 +140,8 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,
-                                const uint32_t* inv_slots, const float* tile_grads,
-                                uint32_t capacity, const uint8_t* clamp_bits, float* color_grads,
+                                const float* tile_grads, const uint8_t* clamp_bits,
+                                float* color_grads,
                                 float* grad2d, float* dL_dmeans,
                                 float* dL_dcov, float* dL_dsh, float* dL_dcolors,
                                 float* dL_dopacity, float* dL_dmeans2D, hipStream_t st);

@@ -17,7 +17,8 @@
 // sort key are integer-valued functions of this arithmetic and must be bit-exact.
 //
 // Record (12 floats per (view, Gaussian), written only when visible):
-//   [0..3] px, py, conic.x, conic.y   [4..7] conic.z, opacity, depth, tiles touched (int bits)
+//   [0..3] px, py, conic.x, conic.y   [4..7] conic.z, opacity, depth, packed small-rect origin
+//          (kSmallFlag | width-1 | ymin | xmin for rects of <= 4 tiles, else 0)
 //   [8..11] r, g, b, clamp bits
 #include "raster_common.h"
 #include "sh_math.h"
@@ -136,7 +137,10 @@ geometry_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
                              (uint32_t)xmax | ((uint32_t)ymax << 16));
       float4* r = reinterpret_cast<float4*>(records + vg * kRecFloats);
       r[0] = make_float4(px, py, con_x, con_y);
-      r[1] = make_float4(con_z, opac, tvz, __int_as_float((xmax - xmin) * (ymax - ymin)));
+      const int rw = xmax - xmin, area = rw * (ymax - ymin);
+      const uint32_t packed = (area <= kInvSlots && gy <= 16383)
+          ? (kSmallFlag | ((uint32_t)(rw - 1) << 29) | ((uint32_t)ymin << 15) | (uint32_t)xmin) : 0u;
+      r[1] = make_float4(con_z, opac, tvz, __uint_as_float(packed));
       if (colors != nullptr) {   // colors_precomp: verbatim, no clamp
         const float* cp = colors + vg * 3;
         r[2] = make_float4(cp[0], cp[1], cp[2], __uint_as_float(0u));

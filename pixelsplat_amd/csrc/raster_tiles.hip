@@ -335,8 +335,24 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   if (l_start > capacity) l_start = capacity;
   const uint32_t* list = point_list + l_start;
 
-  // entries behind the tile's last contributor are never touched (1-based index c_max)
+  // entries behind the tile's last contributor are never blended (1-based index c_max); the
+  // geometry backward still sums the private slot of every (Gaussian, tile) pair of a small
+  // Gaussian, so the slots of those entries are cleared here (nothing is memset)
   const uint32_t c_max = tile_end[tile_global];
+  float4* const slots = reinterpret_cast<float4*>(tile_grads) + vo * (kInvSlots * 3);
+  {
+    uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
+    if (l_count > capacity - l_start) l_count = capacity - l_start;
+    for (uint32_t e = c_max + (uint32_t)lane; e < l_count; e += kWave) {
+      const uint32_t id = list[e];
+      const uint32_t pk = __float_as_uint(recs[(size_t)id * kRecFloats + 7]);
+      if (pk & kSmallFlag) {
+        const uint32_t kk = (ty - ((pk >> 15) & 0x3FFFu)) * (((pk >> 29) & 3u) + 1u) + (tx - (pk & 0x7FFFu));
+        float4* tg = slots + ((size_t)id * kInvSlots + kk) * 3;
+        tg[0] = tg[1] = tg[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
   if (c_max == 0) return;
 
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
@@ -379,10 +395,21 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       keep = qm != 0u;
       q0 = make_float4(r0.x, r0.y, A, B);
       q1 = make_float4(Cq, r1.y, r2.x, r2.y);
-      // bit 4: the Gaussian touches <= 4 tiles -> its partial gradient goes to a private slot
-      const uint32_t small = (uint32_t)__float_as_int(r1.w) <= (uint32_t)kInvSlots ? 16u : 0u;
+      // bit 4: the Gaussian touches <= 4 tiles -> its partial gradient goes to its private
+      // slot of this tile (index id * 4 + position of the tile inside its rect), else id
+      const uint32_t pk = __float_as_uint(r1.w);
+      const uint32_t small = (pk & kSmallFlag) ? 16u : 0u;
+      uint32_t target = id;
+      if (small) {
+        const uint32_t kk = (ty - ((pk >> 15) & 0x3FFFu)) * (((pk >> 29) & 3u) + 1u) + (tx - (pk & 0x7FFFu));
+        target = id * (uint32_t)kInvSlots + kk;
+        if (!keep) {   // cannot reach any quadrant: never blended, its slot is still summed
+          float4* tg = slots + (size_t)target * 3;
+          tg[0] = tg[1] = tg[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
       q2 = make_float4(r2.z, __uint_as_float(top - lane), __uint_as_float(qm | small),
-                       __uint_as_float(id));
+                       __uint_as_float(target));
     }
     const uint64_t mask = __ballot(keep);
     if (keep) {
@@ -454,25 +481,26 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       }
     }
     wave_lds_sync();
-    // lane j finalises entry j: one set of 9 atomics per (tile, Gaussian)
-    if ((uint32_t)lane < m && lds.gsum[lane][9] != 0.f) {
+    // lane j finalises entry j: its private slot (always written: values or zeros), or one set
+    // of 9 atomics per (tile, Gaussian) for the large ones
+    if ((uint32_t)lane < m) {
       const uint32_t slot = (b_head + lane) & (kQB - 1);
       const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
       const float* gs = lds.gsum[lane];
+      const bool hit = gs[9] != 0.f;
       const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
                   cz = q1.x * (-2.f / kLog2e);
       const float Mx = gs[0], My = gs[1];
       const float o0 = (-cx * Mx - cy * My) * ddelx_dx, o1 = (-cz * My - cy * Mx) * ddely_dy;
       const float o2 = -0.5f * gs[2], o3 = -0.5f * gs[3], o4 = -0.5f * gs[4];
       if (__float_as_uint(q2.z) & 16u) {
-        // private slot of this (tile, entry): plain 16-byte stores, summed later in a fixed
+        // private slot of this (Gaussian, tile): plain 16-byte stores, summed later in a fixed
         // order by the geometry backward (no atomics, deterministic)
-        const uint32_t pos = l_start + __float_as_uint(q2.y) - 1u;
-        float4* tg = reinterpret_cast<float4*>(tile_grads + (size_t)pos * kSlotFloats);
-        tg[0] = make_float4(o0, o1, o2, o3);
-        tg[1] = make_float4(o4, gs[5], gs[6], gs[7]);
-        tg[2] = make_float4(gs[8], 0.f, 0.f, 0.f);
-      } else {
+        float4* tg = slots + (size_t)__float_as_uint(q2.w) * 3;
+        tg[0] = hit ? make_float4(o0, o1, o2, o3) : make_float4(0.f, 0.f, 0.f, 0.f);
+        tg[1] = hit ? make_float4(o4, gs[5], gs[6], gs[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        tg[2] = make_float4(hit ? gs[8] : 0.f, 0.f, 0.f, 0.f);
+      } else if (hit) {
         float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
         atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
         atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, gs[5]);
