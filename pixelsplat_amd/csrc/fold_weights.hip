@@ -35,6 +35,13 @@ __device__ __forceinline__ float a_entry(const FoldDims& m, const FoldParams& p,
   return 0.f;
 }
 
+// sum over the four lanes that share one output element
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  return v;
+}
+
 }  // namespace
 
 // K, V [heads][lh][dh] and vb [inner] = W_v b_d.  Identity rows of A are plain copies; the
@@ -122,12 +129,15 @@ __global__ __launch_bounds__(256) void fold_out_kernel(FoldDims m, FoldParams p,
     w_o_t[t] = s;
     return;
   }
-  t -= n_o;
+  t -= n_o;   // n_in + n_o is a multiple of 4: the 4-lane groups below stay aligned
+  const int sub = t & 3;
+  t >>= 2;
   if (t < m.d_out) {
-    float s = p.b_out ? p.b_out[t] : 0.f;
+    float s = 0.f;
 #pragma unroll 8
-    for (int ii = 0; ii < inner; ++ii) s = fmaf(p.w_out[(size_t)t * inner + ii], vb[ii], s);
-    bias[t] = s;
+    for (int ii = sub; ii < inner; ii += 4) s = fmaf(p.w_out[(size_t)t * inner + ii], vb[ii], s);
+    s = quad_sum(s);
+    if (sub == 0) bias[t] = s + (p.b_out ? p.b_out[t] : 0.f);
   }
 }
 
@@ -141,27 +151,31 @@ __global__ __launch_bounds__(256) void fold_back_kv_kernel(FoldDims m, FoldParam
                                                            float* __restrict__ dvb) {
   const int inner = m.heads * m.dh;
   const int n_kv = m.heads * m.lh * m.dh;
-  int t = blockIdx.x * 256 + threadIdx.x;
+  const int T = blockIdx.x * 256 + threadIdx.x, sub = T & 3;   // four lanes per element
+  int t = T >> 2;
   if (t < n_kv) {
     const int j = t % m.dh, hr = t / m.dh, h = hr / m.lh;
     const float* gi = d_w_in + (size_t)hr * m.d;
     const float* wq = p.w_q + (size_t)(h * m.dh + j) * m.d;
     float a = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < m.d; ++k) a = fmaf(gi[k], wq[k], a);
+    for (int k = sub; k < m.d; k += 4) a = fmaf(gi[k], wq[k], a);
     const float* go = d_w_o_t + (size_t)hr * m.d_out;
     float b = 0.f;
 #pragma unroll 8
-    for (int o = 0; o < m.d_out; ++o) b = fmaf(go[o], p.w_out[(size_t)o * inner + h * m.dh + j], b);
-    dK[t] = a; dV[t] = b;
+    for (int o = sub; o < m.d_out; o += 4)
+      b = fmaf(go[o], p.w_out[(size_t)o * inner + h * m.dh + j], b);
+    a = quad_sum(a); b = quad_sum(b);
+    if (sub == 0) { dK[t] = a; dV[t] = b; }
     return;
   }
   t -= n_kv;
   if (t < inner) {
     float s = 0.f;
 #pragma unroll 8
-    for (int o = 0; o < m.d_out; ++o) s = fmaf(p.w_out[(size_t)o * inner + t], d_bias[o], s);
-    dvb[t] = s;
+    for (int o = sub; o < m.d_out; o += 4) s = fmaf(p.w_out[(size_t)o * inner + t], d_bias[o], s);
+    s = quad_sum(s);
+    if (sub == 0) dvb[t] = s;
   }
 }
 
@@ -173,12 +187,6 @@ struct FoldGrads {
 // Four lanes share one output element (the reduction index is split 4 ways and summed with two
 // quad shuffles): with one thread per output this kernel was a chain of ~150 dependent global
 // round trips on ~1 block per CU (240 us; 64 us unrolled).
-__device__ __forceinline__ float quad_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  return v;
-}
-
 __global__ __launch_bounds__(256) void fold_back_params_kernel(
     FoldDims m, FoldParams p, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ vb, const float* __restrict__ dK, const float* __restrict__ dV,
@@ -287,7 +295,7 @@ int launch_fold_forward(const PsFoldDesc& d, const float* w_q, const float* w_kv
   // n_kv is a multiple of 4 (lh is), so the 4-lane groups of the dense part stay aligned
   fold_kv_kernel<<<blocks_for(n_kv + 4 * ((long)m.heads * (m.P + m.ov) * m.dh + inner)), 256, 0, st>>>(
       m, p, K, V, vb);
-  const long n2 = (long)m.heads * m.lh * (m.d + m.d_out) + m.d_out;
+  const long n2 = (long)m.heads * m.lh * (m.d + m.d_out) + 4L * m.d_out;
   fold_out_kernel<<<blocks_for(n2), 256, 0, st>>>(m, p, K, V, vb, w_in, w_o_t, bias);
   return PS_OK;
 }
@@ -304,7 +312,7 @@ int launch_fold_backward(const PsFoldDesc& d, const float* w_q, const float* w_k
   const long n_kv = (long)m.heads * m.lh * m.dh, inner = (long)m.heads * m.dh;
   const float* K = scratch; const float* V = K + n_kv; const float* vb = V + n_kv;
   float* dK = back_scratch; float* dV = dK + n_kv; float* dvb = dV + n_kv;
-  fold_back_kv_kernel<<<blocks_for(n_kv + inner), 256, 0, st>>>(m, p, d_w_in, d_w_o_t, d_bias, dK,
+  fold_back_kv_kernel<<<blocks_for(4 * (n_kv + inner)), 256, 0, st>>>(m, p, d_w_in, d_w_o_t, d_bias, dK,
                                                                  dV, dvb);
   const long n2 = inner * m.d + (long)m.d_out * inner + 2 * inner * m.c +
                   (long)(m.P + m.ov) * m.c + m.c + m.d_out;
