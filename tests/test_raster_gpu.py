@@ -320,3 +320,41 @@ def test_one_call_abi_equals_the_split_calls(gpu_device):
                                      temp.numel(), _p(plist), plist.numel(), _stream()),
                "ps_raster_forward")
     assert torch.equal(color, img_a) and torch.equal(radii, radii_a)
+
+
+@pytest.mark.parametrize("seed,n,hw", [(11, 600, (64, 64)), (12, 1500, (96, 80))])
+def test_opaque_front_layer_and_never_blended_tail(gpu_device, seed, n, hw):
+    """Early termination: a layer of near, almost opaque Gaussians drives T below t_min after a
+    few entries, so most of every tile list is never blended (forward stops, the backward
+    starts at the last contributor).  Those entries' private gradient slots are cleared by the
+    tile backward itself (nothing is memset): every gradient must still match the oracle, and
+    the Gaussians that never contribute must get exactly zero."""
+    sc = small_scene(n, hw, seed=seed, dtype=np.float32, opacity_hi=0.5)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n)
+    front, back = perm[: n // 5], perm[n // 5:]
+    sc["means"][front, 2] = rng.uniform(1.2, 1.6, front.size).astype(np.float32)   # nearest,
+    sc["means"][front, 0] = rng.uniform(-0.8, -0.35, front.size).astype(np.float32)  # left part
+    sc["opacity"][front] = 0.99
+    sc["cov6"][front] *= np.float32(1.5)                                            # and wide
+    sc["cov6"][back] *= np.float32(0.15)   # the rest small: rects of <= 4 tiles (slot path)
+    st = R.forward(dtype=np.float32, **sc)
+    # the scenario really is there: in some tile less than 60 % of the list is ever blended
+    lens = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
+    gx = (hw[1] + 15) // 16
+    nc = st.n_contrib.reshape(hw)
+    last = np.array([nc[(t // gx) * 16:(t // gx) * 16 + 16, (t % gx) * 16:(t % gx) * 16 + 16].max()
+                     for t in range(lens.size)])
+    assert np.any((lens > 20) & (last < 0.6 * lens)), "no tile with a long never-blended tail"
+    dL = rng.normal(size=(3,) + hw).astype(np.float32)
+    ref = R.backward(st, dL)
+    img, radii, g = _single_view_hip(sc, gpu_device, dL)
+    assert np.array_equal(radii, st.radii)
+    assert np.abs(img - st.image).max() < IMG_TOL
+    for name, key in (("means3D", "means3D"), ("cov6", "cov6"), ("opacity", "opacity"),
+                      ("feat", "sh"), ("means2D", "means2D")):
+        _grad_close(g[name], ref[key], name)
+    dead = (np.abs(ref["opacity"]) == 0) & (st.radii > 0)
+    small = (st.tiles_touched <= 4) & (st.radii > 0)
+    assert (dead & small).sum() > 50 and (~dead & small).sum() > 50, "scenario not exercised"
+    assert np.all(g["opacity"][dead] == 0) and np.all(g["means3D"][dead] == 0)
