@@ -22,19 +22,22 @@ def enable(path: str | None = None) -> bool:
 
     if not torch.cuda.is_available():
         return False
-    tun = torch.cuda.tunable
-    tun.enable(True)
-    tun.tuning_enable(False)
-    if hasattr(tun, "write_file_on_exit"):
-        tun.write_file_on_exit(False)
-    else:   # this build always writes its table at exit: send that to the temp directory
-        import tempfile
-        tun.set_filename(os.path.join(tempfile.gettempdir(),
-                                      f"pixelsplat_tunableop_{os.getpid()}.csv"))
     try:
+        tun = torch.cuda.tunable
+        tun.enable(True)
+        tun.tuning_enable(False)
+        if hasattr(tun, "write_file_on_exit"):
+            tun.write_file_on_exit(False)
+        else:   # this build always writes its table at exit: send that to the temp directory
+            import tempfile
+            tun.set_filename(os.path.join(tempfile.gettempdir(),
+                                          f"pixelsplat_tunableop_{os.getpid()}.csv"))
         return bool(tun.read_file(path or TABLE))
-    except Exception:   # malformed / foreign table: keep the defaults
-        tun.enable(False)
+    except Exception:   # no TunableOp in this build, malformed / foreign table: keep the defaults
+        try:
+            torch.cuda.tunable.enable(False)
+        except Exception:
+            pass
         return False
 
 
