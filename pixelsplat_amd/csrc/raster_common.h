@@ -20,8 +20,8 @@ constexpr int kInvSlots = 4;            // Gaussians touching <= 4 tiles use slo
 constexpr uint32_t kSmallFlag = 0x80000000u;
 
 // sort geometry
-constexpr int kSortThreads = 256;
-constexpr int kSortItems = 16;
+constexpr int kSortThreads = 1024;      // 16 waves x 4 items: the per-wave ranking chain is the
+constexpr int kSortItems = 4;           // latency of the scatter kernel (16 items: 62 us per pass)
 constexpr int kSortChunk = kSortThreads * kSortItems;  // 4096 keys per block
 constexpr int kBinChunk = 1024;                        // sorted entries per binning block
 

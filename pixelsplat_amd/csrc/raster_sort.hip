@@ -24,7 +24,7 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
   const int limit = FIRST ? G : (int)n_vis[v];
   const int base = blk * kSortChunk;
   if (base < limit) {
-    h[t] = 0;
+    if (t < 256) h[t] = 0;
     __syncthreads();
     const uint32_t* k = keys + (size_t)v * G;
 #pragma unroll
@@ -37,7 +37,8 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
     }
     __syncthreads();
   }
-  block_hist[((size_t)v * nblk + blk) * 256 + t] = base < limit ? h[t] : 0u;     // [v][blk][digit]
+  if (t < 256)
+    block_hist[((size_t)v * nblk + blk) * 256 + t] = base < limit ? h[t] : 0u;   // [v][blk][digit]
 }
 
 // one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order.
@@ -90,18 +91,18 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                     const uint32_t* __restrict__ block_hist, int G, int nblk, int shift,
                     const uint32_t* __restrict__ n_vis) {
-  __shared__ uint32_t cnt[4][256];   // per-wave running digit counts
-  __shared__ uint32_t base[4][256];  // global start of (wave, digit)
+  constexpr int NW = kSortThreads / kWave;
+  __shared__ uint32_t cnt[NW][256];   // per-wave running digit counts
+  __shared__ uint32_t base[NW][256];  // global start of (wave, digit)
   const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   const int w = t >> 6, lane = t & 63;
   const int limit = IOTA_VALS ? G : (int)n_vis[v];
   if (blk * kSortChunk >= limit) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) cnt[i][t] = 0;
+  for (int i = t; i < NW * 256; i += kSortThreads) (&cnt[0][0])[i] = 0;
   __syncthreads();
 
   const size_t vo = (size_t)v * G;
-  const int start = blk * kSortChunk + w * (kSortChunk / 4);
+  const int start = blk * kSortChunk + w * (kSortChunk / NW);
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
   const uint64_t lt = lanemask_lt();
 #pragma unroll
@@ -130,10 +131,10 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     wave_lds_sync();
   }
   __syncthreads();
-  {
+  if (t < 256) {
     uint32_t b = block_hist[((size_t)v * nblk + blk) * 256 + t];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { base[i][t] = b; b += cnt[i][t]; }
+    for (int i = 0; i < NW; ++i) { base[i][t] = b; b += cnt[i][t]; }
   }
   __syncthreads();
 #pragma unroll
