@@ -85,12 +85,16 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restri
   if (n_vis != nullptr && dgt == 255) n_vis[v] = x;
 }
 
-template <bool IOTA_VALS>
+// LAST: the final pass also writes sorted_rect[pos] = rects[id] (the tile rects in depth order
+// for the binning kernels): the id is in a register here, so the gather's loads fly under the
+// ranking instead of being a kernel of their own (57 us of dependent 8-byte gathers).
+template <bool IOTA_VALS, bool LAST = false>
 __global__ void __launch_bounds__(kSortThreads)
 sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                     const uint32_t* __restrict__ block_hist, int G, int nblk, int shift,
-                    const uint32_t* __restrict__ n_vis) {
+                    const uint32_t* __restrict__ n_vis, const uint2* __restrict__ rects = nullptr,
+                    uint2* __restrict__ sorted_rect = nullptr) {
   constexpr int NW = kSortThreads / kWave;
   __shared__ uint32_t cnt[NW][256];   // per-wave running digit counts
   __shared__ uint32_t base[NW][256];  // global start of (wave, digit)
@@ -104,6 +108,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   const size_t vo = (size_t)v * G;
   const int start = blk * kSortChunk + w * (kSortChunk / NW);
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
+  uint2 rc[LAST ? kSortItems : 1];
   const uint64_t lt = lanemask_lt();
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
@@ -112,6 +117,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     key[i] = valid ? keys_in[vo + p] : 0u;
     if (IOTA_VALS) valid = valid && key[i] != kCulledKey;
     val[i] = valid ? (IOTA_VALS ? (uint32_t)p : vals_in[vo + p]) : 0u;
+    if (LAST) rc[i] = valid ? rects[vo + val[i]] : make_uint2(0u, 0u);
     const uint32_t dg = (key[i] >> shift) & 0xFFu;
     uint64_t mask = __ballot(valid);
 #pragma unroll
@@ -142,21 +148,11 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     if (rank[i] != kCulledKey) {
       const uint32_t dg = (key[i] >> shift) & 0xFFu;
       const uint32_t pos = base[w][dg] + rank[i];
-      keys_out[vo + pos] = key[i];
+      if (!LAST) keys_out[vo + pos] = key[i];   // nobody reads the keys after the last pass
       vals_out[vo + pos] = val[i];
+      if (LAST) sorted_rect[vo + pos] = rc[i];
     }
   }
-}
-
-// sorted_rect[v][pos] = rects[v][sorted_idx[v][pos]] for the visible prefix
-__global__ void __launch_bounds__(256)
-gather_rects_kernel(const uint32_t* __restrict__ sorted_idx, const uint2* __restrict__ rects,
-                    uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, int G) {
-  const int v = blockIdx.y;
-  const uint32_t n = n_vis[v];
-  const size_t vo = (size_t)v * G;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
-    sorted_rect[vo + p] = rects[vo + sorted_idx[vo + p]];
 }
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
@@ -177,19 +173,21 @@ void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint
     hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(256), 0, st, block_hist, m.nblk,
                        pass == 0 ? n_vis : (uint32_t*)nullptr);
     if (pass == 0)
-      hipLaunchKernelGGL(sort_scatter_kernel<true>, grid, block, 0, st, kin, vin, kout, vout,
-                         block_hist, m.G, m.nblk, shift, n_vis);
+      hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, block, 0, st, kin, vin, kout,
+                         vout, block_hist, m.G, m.nblk, shift, n_vis, (const uint2*)nullptr,
+                         (uint2*)nullptr);
+    else if (pass < 3)
+      hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, block, 0, st, kin, vin, kout,
+                         vout, block_hist, m.G, m.nblk, shift, n_vis, (const uint2*)nullptr,
+                         (uint2*)nullptr);
     else
-      hipLaunchKernelGGL(sort_scatter_kernel<false>, grid, block, 0, st, kin, vin, kout, vout,
-                         block_hist, m.G, m.nblk, shift, n_vis);
+      hipLaunchKernelGGL((sort_scatter_kernel<false, true>), grid, block, 0, st, kin, vin, kout,
+                         vout, block_hist, m.G, m.nblk, shift, n_vis, rects, sorted_rect);
     // ping-pong: keys a<->b ; vals: (iota)->b->a->b->sorted_idx
     uint32_t* tk = kin; kin = kout; kout = tk;
     vin = vout;
     vout = (pass == 0) ? vals_a : (pass == 1) ? vals_b : sorted_idx;
   }
-  dim3 ggrid((m.G + 255) / 256 < 1024 ? (m.G + 255) / 256 : 1024, m.V);
-  hipLaunchKernelGGL(gather_rects_kernel, ggrid, dim3(256), 0, st, sorted_idx, rects,
-                     sorted_rect, n_vis, m.G);
 }
 
 }  // namespace ps
