@@ -11,7 +11,6 @@
 namespace ps {
 
 namespace {
-constexpr int kLnLanes = 16;       // lanes per row
 constexpr int kLnMaxChunks = 8;    // float4 chunks per lane -> dim <= 512
 constexpr int kLnRowsPerBlock = 128;
 
