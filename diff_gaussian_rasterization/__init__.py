@@ -81,8 +81,11 @@ class GaussianRasterizer(nn.Module):
 
         g = means3D.shape[0]
         dev = means3D.device
-        tanfov = torch.stack((torch.as_tensor(rs.tanfovx, dtype=torch.float32, device=dev),
-                              torch.as_tensor(rs.tanfovy, dtype=torch.float32, device=dev)))
+        # floats in render_cuda (:102-103, .item()), 0-d / [1] tensors in render_cuda_orthographic
+        # (:196-197)
+        tanfov = torch.stack(
+            (torch.as_tensor(rs.tanfovx, dtype=torch.float32, device=dev).reshape(-1)[0],
+             torch.as_tensor(rs.tanfovy, dtype=torch.float32, device=dev).reshape(-1)[0]))
         vp = pack_view_params(rs.viewmatrix.reshape(1, 4, 4).contiguous(),
                               rs.projmatrix.reshape(1, 4, 4).contiguous(),
                               rs.campos.reshape(1, 3), tanfov.reshape(1, 2),

@@ -164,6 +164,29 @@ def forward(means, cov6, opacity, view, proj, campos, bg, H, W, tanfovx, tanfovy
                         image, final_T, n_contrib)
 
 
+def ambiguity_mask(st: ForwardState, tol_alpha: float = 2e-5, tol_T: float = 1e-4,
+                   tol_power: float = 1e-5) -> np.ndarray:
+    """uint8 [H, W]: pixels whose forward walk evaluates an entry sitting on one of the blend's
+    hard thresholds (bit 0: alpha ~ alpha_min, bit 1: T (1 - alpha) ~ t_min, bit 2: power ~ 0)
+    within the given relative tolerances -- there two correct fp32 implementations may branch
+    differently (see ps_oracle_blend_ambiguity in raster_ref_impl.inc).
+
+    Defaults: an fp32 evaluation of `power` (|terms| up to ~10, three roundings, the
+    log2(e)-scaled coefficients of the HIP kernel) is off by a few 1e-6 absolute = the
+    relative error of alpha; T is a product of up to a few hundred (1 - alpha) factors."""
+    L = lib()
+    dtype = st.dtype
+    suf = "_f32" if dtype == np.float32 else "_f64"
+    real = C.c_float if dtype == np.float32 else C.c_double
+    P = st.params
+    mask = np.zeros(P.H * P.W, np.uint8)
+    pl = st.point_list if st.num_rendered else np.zeros(1, np.uint32)
+    getattr(L, "ps_oracle_blend_ambiguity" + suf)(
+        C.byref(P), _ptr(st.ranges), _ptr(pl), _ptr(st.xy), _ptr(st.conic_opacity),
+        real(tol_alpha), real(tol_T), real(tol_power), _ptr(mask))
+    return mask.reshape(P.H, P.W)
+
+
 def backward(st: ForwardState, dL_dimage):
     """Returns dict(means3D, means2D, cov6, sh|colors, opacity) -- the five gradients the
     reference's autograd needs (SURVEY.md section 8b 'Gradients required')."""

@@ -102,3 +102,117 @@ def loss_modules() -> SimpleNamespace:
         metrics=imp("src.evaluation.metrics"),
         decoder=imp("src.model.decoder.decoder"),
     )
+
+
+class RasterizerRecorder:
+    """Recording stand-in for the absent third-party module `diff_gaussian_rasterization`
+    (requirements.txt:17): the reference's UNMODIFIED cuda_splatting.py imports it
+    (cuda_splatting.py:5-8) and calls it per view (:99-124).  Every call is recorded exactly
+    as the reference hands it over (settings + arguments); the image it returns is rendered
+    by oracle/raster_ref.c, so what comes out of the reference functions is
+    "reference host glue + oracle rasterizer"."""
+
+    def __init__(self, render: bool = True):
+        self.calls: list[dict] = []
+        self.render = render
+
+    def install(self):
+        import typing
+
+        import numpy as np
+        import torch
+        from torch import nn
+
+        rec = self
+
+        class GaussianRasterizationSettings(typing.NamedTuple):
+            image_height: int
+            image_width: int
+            tanfovx: float
+            tanfovy: float
+            bg: torch.Tensor
+            scale_modifier: float
+            viewmatrix: torch.Tensor
+            projmatrix: torch.Tensor
+            sh_degree: int
+            campos: torch.Tensor
+            prefiltered: bool
+            debug: bool
+
+        class GaussianRasterizer(nn.Module):
+            def __init__(self, raster_settings):
+                super().__init__()
+                self.raster_settings = raster_settings
+
+            def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None,
+                        scales=None, rotations=None, cov3D_precomp=None):
+                s = self.raster_settings
+                npf = lambda t: None if t is None else np.ascontiguousarray(
+                    t.detach().cpu().numpy().astype(np.float32))
+                call = dict(
+                    image_height=int(s.image_height), image_width=int(s.image_width),
+                    tanfovx=float(s.tanfovx), tanfovy=float(s.tanfovy), bg=npf(s.bg),
+                    scale_modifier=float(s.scale_modifier), viewmatrix=npf(s.viewmatrix),
+                    projmatrix=npf(s.projmatrix), sh_degree=int(s.sh_degree),
+                    campos=npf(s.campos), campos_stride=tuple(s.campos.stride()),
+                    viewmatrix_contiguous=bool(s.viewmatrix.is_contiguous()),
+                    means3D=npf(means3D), means2D_shape=tuple(means2D.shape),
+                    means2D_requires_grad=bool(means2D.requires_grad), opacities=npf(opacities),
+                    shs=npf(shs), colors_precomp=npf(colors_precomp), cov3D_precomp=npf(cov3D_precomp),
+                    scales=scales, rotations=rotations)
+                h, w = call["image_height"], call["image_width"]
+                if rec.render:
+                    from oracle import raster_ref as R
+
+                    st = R.forward(
+                        means=call["means3D"], cov6=call["cov3D_precomp"],
+                        opacity=call["opacities"][:, 0], view=call["viewmatrix"].reshape(16),
+                        proj=call["projmatrix"].reshape(16), campos=call["campos"], bg=call["bg"],
+                        H=h, W=w, tanfovx=call["tanfovx"], tanfovy=call["tanfovy"],
+                        sh=call["shs"], colors=call["colors_precomp"], sh_degree=call["sh_degree"])
+                    call["image"] = st.image.copy()
+                    call["radii"] = st.radii.copy()
+                    call["ambiguous"] = R.ambiguity_mask(st)
+                    image = torch.from_numpy(st.image.copy())
+                    radii = torch.from_numpy(st.radii.copy())
+                else:
+                    image = torch.zeros((3, h, w))
+                    radii = torch.zeros(means3D.shape[0], dtype=torch.int32)
+                rec.calls.append(call)
+                return image, radii
+
+        mod = types.ModuleType("diff_gaussian_rasterization")
+        mod.GaussianRasterizationSettings = GaussianRasterizationSettings
+        mod.GaussianRasterizer = GaussianRasterizer
+        sys.modules["diff_gaussian_rasterization"] = mod
+        return self
+
+
+def decoder_modules(recorder: RasterizerRecorder) -> SimpleNamespace:
+    """The reference's decoder host code (cuda_splatting.py, decoder_splatting_cuda.py), the
+    spin trajectory of its one rasterizer fixture (scripts/test_splatter.py) and rotate_sh,
+    imported unmodified on top of `recorder` (which must stand in for the rasterizer BEFORE
+    cuda_splatting.py is imported)."""
+    setup(2)
+    recorder.install()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    for name in ("src.dataset", "src.visualization", "src.visualization.camera_trajectory"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF, *name.split("."))]
+            sys.modules[name] = m
+    sys.modules["src.dataset"].DatasetCfg = object
+    for stale in ("src.model.decoder.cuda_splatting", "src.model.decoder.decoder_splatting_cuda"):
+        sys.modules.pop(stale, None)   # re-bind to THIS recorder
+    imp = importlib.import_module
+    return SimpleNamespace(
+        splatting=imp("src.model.decoder.cuda_splatting"),
+        decoder_cuda=imp("src.model.decoder.decoder_splatting_cuda"),
+        decoder=imp("src.model.decoder.decoder"),
+        types=imp("src.model.types"),
+        projection=imp("src.geometry.projection"),
+        spin=imp("src.visualization.camera_trajectory.spin"),
+        sh_rotation=imp("src.misc.sh_rotation"),
+    )

@@ -109,12 +109,17 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
                 image_shape: tuple[int, int], background_color: Tensor, gaussian_means: Tensor,
                 gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
                 gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True,
-                views_per_scene: int = 1, return_aux: bool = False):
+                views_per_scene: int = 1, return_aux: bool = False,
+                view_params: Tensor | None = None):
     """[B,4,4] c2w, [B,3,3], [B], [B], (h,w), [B,3], Gaussians [B/vps, G, ...] -> [B,3,h,w].
 
     With views_per_scene == 1 the call is argument-for-argument the reference's
-    render_cuda (Gaussians given once per view)."""
-    vp = camera_setup(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    render_cuda (Gaussians given once per view).  `view_params` ([B,48], the packed block of
+    `camera_setup` / `pack_view_params`) replaces the camera arguments when given: callers that
+    render the same cameras repeatedly skip the set-up launch, and the parity tests feed the
+    settings recorded from the reference's own host code."""
+    vp = view_params if view_params is not None else camera_setup(
+        extrinsics, intrinsics, near, far, background_color, scale_invariant)
     return _render(vp, image_shape, gaussian_means, gaussian_covariances,
                    gaussian_sh_coefficients, gaussian_opacities, use_sh, views_per_scene,
                    return_aux)

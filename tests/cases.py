@@ -60,6 +60,31 @@ def oracle_view_inputs(g, cams, b: int, v: int, use_sh: bool = True, bg=None,
     return out
 
 
+_GOLDEN_DECODER = None
+
+
+def decoder_golden():
+    """tests/golden/decoder.npz: the reference's decoder host glue run unmodified over a recording
+    rasterizer stand-in (tests/golden/make_decoder_golden.py)."""
+    global _GOLDEN_DECODER
+    if _GOLDEN_DECODER is None:
+        import os
+        _GOLDEN_DECODER = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                               "golden", "decoder.npz"))
+    return _GOLDEN_DECODER
+
+
+def reference_cameras(name: str):
+    """(make_workload kwargs, view block [V,48]) of a full-size parity configuration.  The view
+    block holds the settings the REFERENCE's render_cuda (cuda_splatting.py:64-110) built for the
+    synthetic target cameras of that configuration -- tanfov, transposed view / full-projection
+    matrices, campos, bg, 1/near -- so that oracle and product are both fed by the reference's
+    host glue and not by the product's own camera kernel."""
+    z = decoder_golden()
+    b, h, w, v_ctx, v_tgt, seed = (int(x) for x in z[f"cam_{name}_def"])
+    return dict(b=b, hw=(h, w), v_ctx=v_ctx, v_tgt=v_tgt, seed=seed), z[f"cam_{name}"].copy()
+
+
 def small_scene(n: int = 48, hw=(32, 32), seed: int = 0, dtype=np.float64, sh_degree: int = 4,
                 opacity_hi: float = 0.6):
     """A few well-conditioned Gaussians in front of one camera (for gradient checks)."""

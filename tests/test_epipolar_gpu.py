@@ -20,7 +20,9 @@ def _cams(b, v, seed, hw=(256, 256), yaw=5.0):
 
 
 @pytest.mark.parametrize("b,v,grid,s,seed", [(1, 2, (16, 16), 32, 0), (2, 3, (12, 20), 8, 1),
-                                             (1, 2, (64, 64), 32, 2), (2, 2, (9, 7), 5, 3)])
+                                             (1, 2, (64, 64), 32, 2), (2, 2, (9, 7), 5, 3),
+                                             (1, 3, (64, 64), 32, 4),      # configs[3] rays
+                                             (1, 2, (128, 128), 32, 5)])   # configs[4] rays
 def test_geometry_bit_exact(gpu_device, b, v, grid, s, seed):
     from pixelsplat_amd.epipolar import sample_geometry
 
@@ -132,6 +134,15 @@ def test_fused_attention_vs_reference_golden(gpu_device, name):
     (1, 2, 256, 4, 4, 9, 4, 8),      # channel class 256
     (1, 3, 36, 3, 5, 40, 1, 12),     # c = 36 (class 64 with idle lanes), T = 80 (> 64), 1 head
     (1, 2, 128, 9, 9, 32, 4, 32),    # the paper's per-ray shape
+    # the PAPER shape, one scene of BASELINE configs[1] (config/model/encoder/epipolar.yaml:
+    # c 128, 64x64 rays per view, 32 samples, 4 heads x d_dot 128 = inner 512): R = 8192 rays
+    (1, 2, 128, 64, 64, 32, 4, 128),
+    # one scene of BASELINE configs[3] (3 context views): S' = 64 kv tokens per ray, view
+    # embeddings, R = 12 288 rays
+    (1, 3, 128, 64, 64, 32, 4, 128),
+    # BASELINE configs[4] (512x512 images): 128x128 feature maps -- the feature-gradient kernel's
+    # per-tile ray cull at 4x the tiles and rays (narrow channels keep the CPU side cheap)
+    (1, 2, 16, 128, 128, 8, 2, 8),
 ])
 def test_fused_attention_vs_oracle_and_autograd(gpu_device, dims):
     """Same rel_disparity on both sides (so the PE noise amplification drops out): forward to
@@ -153,7 +164,7 @@ def test_fused_attention_vs_oracle_and_autograd(gpu_device, dims):
              w_out=torch.randn(c, inner) * 0.3, b_out=torch.randn(c) * 0.1,
              depth_w=torch.randn(c, 20) * 0.3, depth_b=torch.randn(c) * 0.1,
              view_emb=torch.randn(v - 1, c) * 0.3)
-    if c == 128:       # the 2-view configs have no view embedding (epipolar_transformer.py:126)
+    if c == 128 and v == 2:  # the 2-view configs have no view embedding (epipolar_transformer.py:126)
         del P["view_emb"]
     x = torch.randn(b * v * h * w, 1, c)
     gout = torch.randn(b * v * h * w, 1, c)
@@ -336,7 +347,9 @@ def test_invert_cameras(gpu_device):
 
 
 @pytest.mark.parametrize("heads,dh,c,d,d_out,octaves,ov,bias", [
-    (4, 32, 128, 128, 128, 10, 0, True), (2, 8, 20, 12, 16, 3, 2, True), (3, 5, 17, 9, 17, 1, 1, False)])
+    (4, 32, 128, 128, 128, 10, 0, True), (2, 8, 20, 12, 16, 3, 2, True), (3, 5, 17, 9, 17, 1, 1, False),
+    (4, 128, 128, 128, 128, 10, 0, True),     # the paper's layer: inner = 512 (configs[1])
+    (4, 128, 128, 128, 128, 10, 2, True)])    # + view embeddings (configs[3], 3 context views)
 def test_fold_weights_kernels_vs_torch(gpu_device, heads, dh, c, d, d_out, octaves, ov, bias):
     """ps_fold_attention_weights (+ backward) against the torch statement of the same algebra
     (fold_attention_weights_torch, itself checked against the unfused attention on the CPU)."""
