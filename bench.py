@@ -42,6 +42,10 @@ def parse():
     p.add_argument("--size", type=int, default=256)
     p.add_argument("--views", type=int, default=4, help="target views per scene")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--grad-payload-mb", type=float, default=0.0,
+                   help="N > 1: extra synthetic fp32 gradient payload all-reduced per step, to model "
+                        "the rest of the network (the reference reduces ~480 MB; SURVEY.md 5)")
+    p.add_argument("--bucket-mb", type=float, default=25.0, help="gradient bucket size (torch DDP default)")
     p.add_argument("--cpu-views", type=int, default=16, help="views in the CPU-baseline sample")
     return p.parse_args()
 
@@ -167,7 +171,14 @@ def main():
     args = parse()
     from pixelsplat_amd import parallel as P
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks of this node (the same
+        # torch.distributed.run command line the driver uses), one process per GPU over RCCL
+        sys.exit(P.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     rank, world, local = P.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s); "
+              f"reporting n_gpus = {world}", file=sys.stderr)
     dev = torch.device("cuda", local)
 
     from pixelsplat_amd import _lib, gemm_tuning
@@ -201,7 +212,7 @@ def main():
     from pixelsplat_amd.encoder.epipolar_transformer import (EpipolarTransformer,
                                                              EpipolarTransformerCfg,
                                                              ImageSelfAttentionCfg)
-    torch.manual_seed(P.rank_seed(0, rank))
+    torch.manual_seed(0)    # data parallel: identical weights on every rank, different batches
     d_feat, down, n_samp, heads = 128, 4, 32, 4
     et = EpipolarTransformer(EpipolarTransformerCfg(
         self_attention=ImageSelfAttentionCfg(patch_size=4, num_octaves=10, num_layers=2,
@@ -209,6 +220,7 @@ def main():
         num_octaves=10, num_layers=2, num_heads=heads, num_samples=n_samp, d_dot=128, d_mlp=256,
         downscale=down), d_feat, num_context_views=2).to(dev)
     hA, wA = hw[0] // down, hw[1] // down
+    torch.manual_seed(P.rank_seed(0, rank))
     feat = torch.randn(b, 2, hA, wA, d_feat, device=dev).requires_grad_(True)   # channels-last
     c_ext, c_intr = ctx.extrinsics.to(dev), ctx.intrinsics.to(dev)
     c_near, c_far = ctx.near.to(dev), ctx.far.to(dev)
@@ -233,10 +245,21 @@ def main():
         for t in (means, cov, sh, op, feat, *a_params):
             t.grad = None
 
+    # the data-parallel collective of the step: bucketed asynchronous all-reduce
+    # (mean) of the path's parameter gradients over RCCL; a no-op for one rank
+    reducer = P.GradientReducer(a_params, world, bucket_bytes=int(args.bucket_mb * (1 << 20)),
+                                extra_payload_bytes=int(args.grad_payload_mb * 1e6))
+
     def step(a=True, b_=True):
         zero_grads()
-        loss = (path_a() if a else 0.0) + (path_b() if b_ else 0.0)
-        loss.backward()
+        la = path_a() if a else None
+        lb = path_b() if b_ else None
+        if la is not None:
+            la.backward()                 # (A): the parameter gradients land -> buckets launch
+            reducer.launch_extra_payload()
+        if lb is not None:
+            lb.backward()                 # (B): rasterizer backward runs over the reduction
+        reducer.finish()
 
     # ---- Gaussian adapter, timed on its own after the contract's region:
     # the producer of the rasterizer's inputs at the same shape (b x 2 views x HxW rays x 3)
@@ -434,6 +457,14 @@ def main():
                 "epipolar_reference_equivalent_tflops": round(
                     3.0 * 2 * (2.0 * RA * (2 * d_feat * 512 + TA * d_feat * 1024 + 2 * 4 * TA * 128))
                     / (ms_a * 1e-3) / 1e12, 1),
+            },
+            "comm": {
+                "backend": (torch.distributed.get_backend() if world > 1 else None),
+                "world_size": world, "collective": "all_reduce(mean) of the path's parameter gradients, "
+                "bucketed, asynchronous under the rasterizer backward (parallel.GradientReducer)",
+                "gradient_bytes_per_step": 4 * sum(p_.numel() for p_ in a_params),
+                "extra_payload_bytes_per_step": int(args.grad_payload_mb * 1e6),
+                "bucket_mb": args.bucket_mb, **{k_: v_ for k_, v_ in reducer.stats.items()},
             },
             "whole_path": {
                 # (B)'s reference-algorithm bytes over (B)'s own step time

@@ -177,8 +177,10 @@ color_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
   uint32_t vis_bits = 0;
   for (int j = 0; j < vps && j < 32; ++j)
     if (active && radii[(size_t)(s * vps + j) * G + g] > 0) vis_bits |= 1u << j;
-  if (vps > 32) vis_bits = active ? 0xFFFFFFFFu : 0u;
-  if (__ballot(vis_bits != 0u) == 0ull) return;
+  // views beyond the 32 tracked bits are re-tested in the loop below; only the wave-level
+  // early-out must not fire on their behalf
+  const bool any_vis = vps > 32 ? active : vis_bits != 0u;
+  if (__ballot(any_vis) == 0ull) return;
 
   __shared__ __attribute__((aligned(16))) float slab[LDS_SH ? GPW * 75 + 4 : 4];
   const float* my_sh;

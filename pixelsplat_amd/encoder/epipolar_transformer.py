@@ -143,16 +143,27 @@ class EpipolarTransformer(nn.Module):
         if num_context_views > 2:
             self.view_embeddings = nn.Embedding(num_context_views, d_in)
 
+    @property
+    def _kernel_octaves(self) -> int:
+        """Octaves the fused kernels run with: num_octaves = 0 (kv = sampled features only,
+        epipolar_transformer.py:100-121, re10k_ablation_no_depth_encoding.yaml:29) is one octave
+        with zero encoding weights -- the kernel adds exactly 0.0 to every token."""
+        return max(self.cfg.num_octaves, 1)
+
     def _layer_weights(self, attn: nn.Module, view_emb=None) -> dict:
         a = attn.fn
-        lin = self.depth_encoding[1]
+        c = a.to_kv.weight.shape[1]
+        if self.cfg.num_octaves > 0:
+            depth_w, depth_b = self.depth_encoding[1].weight, self.depth_encoding[1].bias
+        else:
+            z = a.to_kv.weight.new_zeros((c, 3))
+            depth_w, depth_b = z[:, :2], z[:, 2]
         to_out = a.to_out[0] if isinstance(a.to_out, nn.Sequential) else None
-        c = lin.weight.shape[0]
         return dict(w_q=a.to_q.weight, w_kv=a.to_kv.weight,
                     w_out=(to_out.weight if to_out is not None else
-                           torch.eye(c, device=lin.weight.device, dtype=lin.weight.dtype)),
+                           torch.eye(c, device=depth_w.device, dtype=depth_w.dtype)),
                     b_out=(to_out.bias if to_out is not None else None), heads=a.heads,
-                    depth_w=lin.weight, depth_b=lin.bias, view_emb=view_emb)
+                    depth_w=depth_w, depth_b=depth_b, view_emb=view_emb)
 
     def fold_layers(self, view_emb=None) -> list:
         """Folded weight matrices of every cross-attention layer, computed on a side stream:
@@ -167,6 +178,9 @@ class EpipolarTransformer(nn.Module):
         folds = []
         with torch.cuda.stream(side):
             for attn, _ in self.transformer.layers:
+                if len(attn.fn.attend._forward_hooks) > 0:
+                    folds.append(None)        # hooked layers take the unfused path: nothing to fold
+                    continue
                 f = fold_attention_weights(**self._layer_weights(attn, view_emb))
                 done = torch.cuda.Event()
                 done.record(side)
@@ -182,7 +196,7 @@ class EpipolarTransformer(nn.Module):
         if folded is not None and len(folded) == 4:
             torch.cuda.current_stream().wait_event(folded[3])
             folded = folded[:3]
-        return fused_cross_attention(layer_norm(x, attn.norm), fmap, geo, octaves=self.cfg.num_octaves,
+        return fused_cross_attention(layer_norm(x, attn.norm), fmap, geo, octaves=self._kernel_octaves,
                                      folded=folded, batch=batch,
                                      **self._layer_weights(attn, view_emb))
 
@@ -194,15 +208,12 @@ class EpipolarTransformer(nn.Module):
             torch.cuda.current_stream().wait_event(folded[3])
             folded = folded[:3]
         xn, xr = layer_norm_fork(x, attn.norm)
-        return fused_cross_attention(xn, fmap, geo, octaves=self.cfg.num_octaves, folded=folded,
+        return fused_cross_attention(xn, fmap, geo, octaves=self._kernel_octaves, folded=folded,
                                      batch=batch, **self._layer_weights(attn, view_emb)) + xr
 
     def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor, materialize_sampling: bool = False,
                 view_shuffle: Optional[Tensor] = None) -> tuple[Tensor, EpipolarSampling]:
-        if self.cfg.num_octaves <= 0:
-            raise NotImplementedError("the fused path always adds the depth encoding "
-                                      "(every reference config has num_octaves = 10)")
         b, v, c, _, _ = features.shape
         if self.downscaler is not None:
             features = self.downscaler(features.flatten(0, 1)).unflatten(0, (b, v))
@@ -230,7 +241,9 @@ class EpipolarTransformer(nn.Module):
             a = attn.fn
             if len(a.attend._forward_hooks) > 0:
                 if kv is None:   # unfused formulation so the hook sees the attention weights
-                    kv = sampled + self.depth_encoding(geo.rel_disparity[..., None])
+                    kv = sampled
+                    if self.cfg.num_octaves > 0:
+                        kv = kv + self.depth_encoding(geo.rel_disparity[..., None])
                     if view_emb is not None:
                         kv = kv + view_emb[None, None, :, None, None, :]
                     kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)

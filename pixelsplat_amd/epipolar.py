@@ -228,6 +228,16 @@ class FeatureGradBatch:
     def park(self, qin, attn, dout, ds):
         self.pending.append((qin, attn, dout, ds))
 
+    def __del__(self):
+        # the first-registered layer never ran its backward (its output was detached or unused)
+        # while later layers parked their terms: those feature-map gradients were NOT applied
+        if getattr(self, "pending", None):
+            import warnings
+            warnings.warn(f"FeatureGradBatch dropped the feature-map gradients of "
+                          f"{len(self.pending)} attention layer(s): the first layer of the batch "
+                          f"did not take part in the backward pass (layers must be chained)",
+                          RuntimeWarning)
+
     def flush(self, desc, fmap, xy, flags, c):
         lib = _lib.load()
         total = None

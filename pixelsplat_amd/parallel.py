@@ -1,9 +1,17 @@
 """One process per GPU, data parallel over independent scenes.
 
-The hot path has no data-path collective: every rank renders its own batch.  What lives
-here is only the launch contract plumbing `bench.py` and training scripts share: rendezvous
-from the torchrun environment (RCCL = backend "nccl" on ROCm; gloo on CPU for tests),
-barrier, max-over-ranks timing, per-rank seeds (the reference seeds per rank too:
+The kernels of the hot path never communicate: every rank renders its own batch of scenes.
+The one collective of a data-parallel training step is the gradient all-reduce of the
+parameters -- the reference gets it from Lightning's `ddp_find_unused_parameters_true`
+(/root/reference/src/main.py:94-98: torch DDP, 25 MB buckets, NCCL) -- and `GradientReducer`
+below is that step for this path on RCCL over xGMI: flat fp32 buckets filled by
+post-accumulate hooks, each all-reduced asynchronously the moment its last gradient lands (so
+the reduction of path (A)'s 6.6 M parameters runs under the rasterizer's backward), unused
+parameters contributing zeros, one wait at the end of the step.
+
+Also here: the launch contract plumbing `bench.py` and training scripts share -- rendezvous from
+the torchrun environment (RCCL = backend "nccl" on ROCm; gloo on CPU for tests), self-launch of
+N ranks, barrier, max-over-ranks timing, per-rank seeds (the reference seeds per rank too:
 /root/reference/src/main.py:106, src/dataset/data_module.py:83-88).
 """
 from __future__ import annotations
@@ -27,11 +35,17 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PIXELSPLAT_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate
+            # devices) -- how the N > 1 bench path is exercised on a single-GPU box
+            backend = os.environ.get("PIXELSPLAT_DIST_BACKEND") or (
+                "nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
+            if torch.cuda.is_available():
+                local = local % torch.cuda.device_count()
+                torch.cuda.set_device(local)
             dist.init_process_group(backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(0)
@@ -72,3 +86,162 @@ def shutdown(world: int) -> None:
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def launch_ranks(n: int, script: str, argv: list[str], timeout: float | None = None) -> int:
+    """Re-runs `script argv` as `n` ranks of one node (`python bench.py --gpus N` without a
+    launcher): the same command line `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node n --master-addr 127.0.0.1 --master-port P script argv` the driver uses,
+    with a free port.  Returns the launcher's exit code; the ranks' stdout passes through."""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
+class GradientReducer:
+    """Bucketed, asynchronous all-reduce of parameter gradients -- what torch DDP does for the
+    reference (main.py:94-98), hand-rolled so that it serves operators that are not one
+    nn.Module.forward (the fused blocks of path (A) are called piecewise) and so that the
+    launch point is explicit.
+
+    * Buckets are flat fp32 buffers of at most `bucket_bytes`, filled in REVERSE parameter order
+      (gradients arrive roughly in reverse order of use).  A post-accumulate hook copies each
+      gradient into its slice, re-points `p.grad` at the slice (gradient-as-bucket-view: the
+      optimizer reads reduced values without a copy back) and, when the bucket is complete,
+      launches ONE `all_reduce(SUM, async)` on it after pre-dividing by the world size (mean).
+      On RCCL the collective runs on the communicator's own stream, ordered after the gradient
+      copies and overlapping whatever the compute stream does next.
+    * `finish()` -- once per step, after the last backward -- launches the buckets that are still
+      incomplete with zeros for the parameters that got no gradient (`find_unused_parameters`
+      semantics: a parameter unused on this rank still takes part, other ranks may have used
+      it), waits for every collective, and re-arms the hooks.
+    * `extra_payload_bytes` adds a dummy buffer that `launch_extra_payload()` reduces in
+      `bucket_bytes` pieces (asynchronously, awaited by `finish()`): it models the gradients of
+      the rest of the network (the reference reduces ~0.48 GB per step) when only
+      the hot path's own parameters exist.
+    * world == 1: hooks are not installed, `finish()` is a no-op.
+    """
+
+    def __init__(self, params, world: int, bucket_bytes: int = 25 << 20, average: bool = True,
+                 extra_payload_bytes: int = 0):
+        self.world = world
+        self.average = average
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets: list[dict] = []
+        self._where: dict[int, tuple[int, int]] = {}
+        self._works: list = []
+        self._hooks = []
+        self.stats = dict(buckets=0, bytes_per_step=0, launches=0, steps=0)
+        if world <= 1 or not self.params:
+            return
+        cur, cur_n = [], 0
+        groups = []
+        for p in reversed(self.params):
+            n = p.numel()
+            if cur and (cur_n + n) * 4 > bucket_bytes:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += n
+        if cur:
+            groups.append(cur)
+        for bi, grp in enumerate(groups):
+            total = sum(p.numel() for p in grp)
+            flat = torch.zeros(total, dtype=torch.float32, device=grp[0].device)
+            off = 0
+            views = []
+            for p in grp:
+                if p.dtype != torch.float32:
+                    raise TypeError("GradientReducer: fp32 parameters only (the path is fp32)")
+                self._where[id(p)] = (bi, len(views))
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self.buckets.append(dict(flat=flat, params=grp, views=views, ready=[False] * len(grp),
+                                     pending=len(grp), launched=False))
+        self.extra = None
+        if extra_payload_bytes > 0:
+            self.extra = torch.zeros(extra_payload_bytes // 4, dtype=torch.float32,
+                                     device=self.params[0].device)
+            self.extra_chunk = max(1, bucket_bytes // 4)
+        self.stats["buckets"] = len(self.buckets)
+        self.stats["bytes_per_step"] = 4 * sum(b["flat"].numel() for b in self.buckets) + \
+            (0 if self.extra is None else 4 * self.extra.numel())
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _launch(self, b: dict) -> None:
+        import torch.distributed as dist
+
+        if self.average:
+            b["flat"].div_(self.world)
+        self._works.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
+        b["launched"] = True
+        self.stats["launches"] += 1
+
+    def _on_grad(self, p: torch.Tensor) -> None:
+        bi, slot = self._where[id(p)]
+        b = self.buckets[bi]
+        if b["launched"]:
+            raise RuntimeError("GradientReducer: a gradient arrived after its bucket was reduced "
+                               "(two backward passes through the same parameter in one step: "
+                               "call finish() between them or accumulate before reducing)")
+        view = b["views"][slot]
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+        if not b["ready"][slot]:
+            b["ready"][slot] = True
+            b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def launch_extra_payload(self) -> None:
+        """All-reduce of the synthetic payload (the rest of the network's gradients), in
+        bucket-sized pieces, asynchronously; call where that backward would run."""
+        if self.world <= 1 or self.extra is None:
+            return
+        import torch.distributed as dist
+
+        for off in range(0, self.extra.numel(), self.extra_chunk):
+            self._works.append(dist.all_reduce(self.extra[off:off + self.extra_chunk],
+                                               op=dist.ReduceOp.SUM, async_op=True))
+            self.stats["launches"] += 1
+
+    def finish(self) -> None:
+        """End of the step: reduce what is still incomplete (unused parameters count as zero),
+        wait for every collective, re-arm."""
+        if self.world <= 1 or not self.params:
+            return
+        for b in self.buckets:
+            if not b["launched"]:
+                for slot, ok in enumerate(b["ready"]):
+                    if not ok:
+                        b["views"][slot].zero_()
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        for b in self.buckets:
+            # a parameter unused on THIS rank still receives the other ranks' mean gradient
+            for p, view, ok in zip(b["params"], b["views"], b["ready"]):
+                if not ok:
+                    p.grad = view
+            b["ready"] = [False] * len(b["params"])
+            b["pending"] = len(b["params"])
+            b["launched"] = False
+        self.stats["steps"] += 1
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()

@@ -107,6 +107,19 @@ class ForwardResult:
     overflow_event: object | None = None
     bwd_temp: tuple | None = None  # (zeroed backward temp buffer, its event) when grads are wanted
 
+    def check_overflow(self, capacity: int) -> None:
+        """Fixed-capacity mode: waits for the forward's 8-byte flag copy and raises when the
+        tile lists did not fit (the image was then blended from truncated lists).  No-op in
+        exact-sizing mode."""
+        if self.overflow_host is None:
+            return
+        self.overflow_event.synchronize()
+        if int(self.overflow_host[1]) != 0:
+            raise RuntimeError(
+                f"pixelsplat_amd.rasterize: {int(self.overflow_host[0])} tile-list entries exceed "
+                f"list_capacity={capacity} (PS_ERR_CAPACITY); raise it or use list_capacity=0 "
+                f"(exact sizing)")
+
 
 def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
              want_backward: bool = False) -> ForwardResult:
@@ -207,6 +220,10 @@ class _Rasterize(torch.autograd.Function):
         view_params = view_params.contiguous()
         r = _forward(cfg, means, cov, opacity, sh, colors, view_params,
                      want_backward=any(ctx.needs_input_grad))
+        if not any(ctx.needs_input_grad):
+            # inference (no backward will ever read the flag): check the capacity now, one
+            # host wait on an 8-byte copy that was queued right behind the forward
+            r.check_overflow(cfg.list_capacity)
         ctx.bwd_temp = r.bwd_temp
         ctx.cfg = cfg
         ctx.has_means2d = means2d is not None
@@ -224,13 +241,8 @@ class _Rasterize(torch.autograd.Function):
         d = cfg.desc()
         V, dev = cfg.n_views, means.device
         flag, ev = ctx.overflow
-        if flag is not None:
-            ev.synchronize()  # long complete: the copy was queued right after the forward
-            if int(flag[1]) != 0:
-                raise RuntimeError(
-                    f"pixelsplat_amd.rasterize: {int(flag[0])} tile-list entries exceed "
-                    f"list_capacity={cfg.list_capacity} (PS_ERR_CAPACITY); raise it or use "
-                    f"list_capacity=0 (exact sizing)")
+        if flag is not None:   # long complete: the copy was queued right after the forward
+            ForwardResult(None, None, None, None, None, flag, ev).check_overflow(cfg.list_capacity)
         dL_dcolor = dL_dcolor.contiguous()
         g_means = torch.empty_like(means)
         g_cov = torch.empty_like(cov)
@@ -264,6 +276,11 @@ def rasterize(cfg: RasterConfig, means: Tensor, cov: Tensor, opacity: Tensor,
     `pack_view_params`); sh [S,G,K,3] | [S,G,3,K] xor colors [V,G,3]; means2d [V,G,3]
     (optional, only to receive the screen-space gradient).
     Returns (color [V,3,H,W], radii [V,G] int32).
+
+    With `cfg.list_capacity > 0` (no host sync in the forward) an overflow of the tile lists is
+    raised from backward(); a call that needs no gradients (inference, `torch.no_grad()`) checks
+    the flag before returning instead, and `forward_with_state(...)[0].check_overflow(capacity)`
+    does the same for the raw forward.
     """
     if (sh is None) == (colors is None):
         raise Exception("Please provide exactly one of either SHs or precomputed colors!")

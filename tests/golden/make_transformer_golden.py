@@ -18,10 +18,10 @@ CFG = dict(num_octaves=10, num_layers=2, num_heads=2, num_samples=4, d_dot=8, d_
 SA = dict(patch_size=2, num_octaves=4, num_layers=1, num_heads=2, d_token=16, d_dot=8, d_mlp=32)
 
 
-def one(name, v, seed):
+def one(name, v, seed, **over):
     m = RI.modules(v)
     cfg = m.transformer.EpipolarTransformerCfg(
-        self_attention=m.self_attention.ImageSelfAttentionCfg(**SA), **CFG)
+        self_attention=m.self_attention.ImageSelfAttentionCfg(**SA), **{**CFG, **over})
     torch.manual_seed(seed)
     net = m.transformer.EpipolarTransformer(cfg, 16)
     gen = torch.Generator().manual_seed(seed)
@@ -45,3 +45,5 @@ def one(name, v, seed):
 if __name__ == "__main__":
     one("transformer_v2.npz", 2, 0)
     one("transformer_v3.npz", 3, 1)
+    # config/experiment/re10k_ablation_no_depth_encoding.yaml:29 -- kv = sampled features only
+    one("transformer_v3_no_depth_encoding.npz", 3, 2, num_octaves=0)

@@ -50,3 +50,92 @@ def test_single_rank_is_a_noop():
     assert P.env_rank() == (0, 1, 0)
     assert P.max_over_ranks(3.5, 1) == 3.5
     assert P.aggregate_throughput(28, 20, 1, 0.14) == 28 * 20 / 0.14
+
+
+# ---- gradient all-reduce (GradientReducer) ---------------------------------------------
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from pixelsplat_amd import parallel as P
+
+    P.init_from_env("gloo")
+    torch.manual_seed(0)                       # same initial weights on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16),
+                              torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    unused_here = torch.nn.Parameter(torch.ones(7))     # used by rank 0 only
+    never_used = torch.nn.Parameter(torch.ones(3))
+    params = list(net.parameters()) + [unused_here, never_used]
+    # 400-byte buckets: several buckets, some holding more than one tensor
+    red = P.GradientReducer(params, world, bucket_bytes=400)
+    gen = torch.Generator().manual_seed(100)
+    x_all, y_all = torch.randn(8, 6, generator=gen), torch.randn(8, 3, generator=gen)
+    half = slice(rank * 4, rank * 4 + 4)
+    results = []
+    for step in range(2):                      # twice: the hooks re-arm after finish()
+        for p in params:
+            p.grad = None
+        loss = (net(x_all[half]) - y_all[half]).square().mean()
+        if rank == 0:
+            loss = loss + (unused_here * torch.arange(7.0)).sum()
+        loss.backward()
+        red.finish()
+        results.append([p.grad.clone() for p in params])
+    out[rank] = (results, dict(red.stats))
+    P.shutdown(world)
+
+
+def test_gradient_reducer_two_ranks_equals_single_process():
+    """Two gloo ranks, each with half of a batch: the reduced gradients equal the single-process
+    gradients of the whole batch (mean of the two half-batch means), bucket by bucket; a parameter
+    used on one rank only gets that rank's gradient / world on BOTH ranks
+    (find_unused_parameters semantics, /root/reference/src/main.py:95), one used nowhere zeros."""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_reducer_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16),
+                              torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    gen = torch.Generator().manual_seed(100)
+    x_all, y_all = torch.randn(8, 6, generator=gen), torch.randn(8, 3, generator=gen)
+    (net(x_all) - y_all).square().mean().backward()
+    ref = [p.grad for p in net.parameters()] + [torch.arange(7.0) / 2, torch.zeros(3)]
+    for rank in range(world):
+        results, stats = res[rank]
+        assert stats["buckets"] >= 3 and stats["launches"] == 2 * stats["buckets"]
+        assert stats["bytes_per_step"] == 4 * sum(r.numel() for r in ref)
+        for step_grads in results:
+            for got, want in zip(step_grads, ref):
+                torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-7)
+    for a, b in zip(res[0][0][1], res[1][0][1]):
+        assert torch.equal(a, b)                # every rank holds the same reduced gradient
+
+
+def test_gradient_reducer_single_rank_is_transparent():
+    from pixelsplat_amd import parallel as P
+    w = torch.nn.Parameter(torch.ones(4))
+    red = P.GradientReducer([w], 1)
+    (w * 3).sum().backward()
+    red.finish()
+    red.launch_extra_payload()
+    assert torch.equal(w.grad, torch.full((4,), 3.0)) and red.stats["launches"] == 0
+
+
+def test_launch_ranks_runs_the_script_as_n_ranks(capfd):
+    """`python bench.py --gpus N` without a launcher re-executes itself through
+    torch.distributed.run; here the same helper launches a two-rank CPU stand-in."""
+    import json
+    import sys
+    from pixelsplat_amd import parallel as P
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_probe.py")
+    rc = P.launch_ranks(2, probe, ["--steps", "3"], timeout=300)
+    assert rc == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                      # rank 0 alone prints the JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["t"] == 2.0 and rec["out"] == ["--steps", "3"]
+    assert rec["grad"] == [0.0, 1.5, 3.0, 4.5, 6.0]     # mean of (1x, 2x) arange

@@ -358,3 +358,64 @@ def test_opaque_front_layer_and_never_blended_tail(gpu_device, seed, n, hw):
     small = (st.tiles_touched <= 4) & (st.radii > 0)
     assert (dead & small).sum() > 50 and (~dead & small).sum() > 50, "scenario not exercised"
     assert np.all(g["opacity"][dead] == 0) and np.all(g["means3D"][dead] == 0)
+
+
+def test_fixed_capacity_overflow_is_raised_in_inference(gpu_device):
+    """list_capacity too small: a call WITHOUT gradients (inference) must raise from the forward
+    -- no backward will ever read the flag -- a call with gradients from backward()."""
+    import dataclasses
+
+    from pixelsplat_amd import _lib
+    from pixelsplat_amd.decoder import camera_setup
+    from pixelsplat_amd.raster import RasterConfig, forward_with_state, rasterize
+
+    dev = gpu_device
+    ctx, tgt, g, _ = make_workload(1, (64, 64), v_ctx=2, v_tgt=2, seed=2)
+    V = 2
+    means, cov = g.means.to(dev), g.covariances.to(dev)
+    sh, op = g.harmonics.to(dev), g.opacities.to(dev)
+    vp = camera_setup(tgt.extrinsics.reshape(V, 4, 4).to(dev), tgt.intrinsics.reshape(V, 3, 3).to(dev),
+                      tgt.near.reshape(V).to(dev), tgt.far.reshape(V).to(dev), torch.zeros(V, 3, device=dev))
+    cfg = RasterConfig(n_scenes=1, views_per_scene=V, n_gaussians=means.shape[1], height=64, width=64,
+                       sh_degree=4, sh_coeffs=25, sh_layout=_lib.PS_SH_G3K, cov_layout=_lib.PS_COV_33,
+                       list_capacity=1000)
+    with pytest.raises(RuntimeError, match="list_capacity"):
+        with torch.no_grad():
+            rasterize(cfg, means, cov, op, vp, sh=sh)
+    res, _ = forward_with_state(cfg, means, cov, op, vp, sh=sh)
+    with pytest.raises(RuntimeError, match="list_capacity"):
+        res.check_overflow(cfg.list_capacity)
+    leaf = means.clone().requires_grad_(True)
+    img, _ = rasterize(cfg, leaf, cov, op, vp, sh=sh)            # training: raised in backward
+    with pytest.raises(RuntimeError, match="list_capacity"):
+        img.sum().backward()
+    big = dataclasses.replace(cfg, list_capacity=400000)
+    with torch.no_grad():
+        ok_img, _ = rasterize(big, means, cov, op, vp, sh=sh)
+        exact, _ = rasterize(dataclasses.replace(cfg, list_capacity=0), means, cov, op, vp, sh=sh)
+    assert torch.equal(ok_img, exact)
+
+
+def test_more_than_32_views_per_scene(gpu_device):
+    """views_per_scene > 32 (video / evaluation renders): the colour kernel tracks visibility in
+    a 32-bit mask and re-tests the views beyond it (the mask used to be overwritten
+    with all-ones).  Views 0, 31, 32 and 39 of 40 against the oracle."""
+    from pixelsplat_amd.decoder import render_cuda
+
+    dev = gpu_device
+    hw, V = (32, 48), 40
+    ctx, tgt, g, _ = make_workload(1, (16, 16), v_ctx=2, v_tgt=V, seed=6)
+    img, aux = render_cuda(
+        tgt.extrinsics.reshape(V, 4, 4).to(dev), tgt.intrinsics.reshape(V, 3, 3).to(dev),
+        tgt.near.reshape(V).to(dev), tgt.far.reshape(V).to(dev), hw, torch.zeros(V, 3, device=dev),
+        g.means.to(dev), g.covariances.to(dev), g.harmonics.to(dev), g.opacities.to(dev),
+        views_per_scene=V, return_aux=True)
+    img = img.cpu().numpy()
+    vps = aux["view_params"].cpu().numpy()
+    radii = aux["radii"].cpu().numpy()
+    assert np.isfinite(img).all()
+    for v in (0, 31, 32, 39):
+        st = R.forward(H=hw[0], W=hw[1], **oracle_view_inputs(g, tgt, 0, v, view_params=vps[v]))
+        assert np.array_equal(radii[v], st.radii)
+        ok = R.ambiguity_mask(st) == 0
+        assert np.abs(img[v] - st.image).max(0)[ok].max() <= IMG_TOL
