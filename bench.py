@@ -109,7 +109,7 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     R.parallel_backward(True)
     cores = os.cpu_count() or 1
     t_total = 0.0
-    linf, mse, n_over, n_pix = 0.0, [], 0, 0
+    linf_all, linf_ok, mse, n_over, n_marked, n_pix = 0.0, 0.0, [], 0, 0, 0
     vps = tgt.near.shape[1]
     for v in range(n_views):
         inp = oracle_view_inputs(gaussians, tgt, v // vps, v % vps, view_params=vps_np[v])
@@ -118,9 +118,12 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
         R.backward(st, dL[v])
         t_total += time.perf_counter() - t0
         diff = np.clip(gpu_images[v], 0, 1) - np.clip(st.image, 0, 1)
-        err = np.abs(gpu_images[v] - st.image)
-        linf = max(linf, float(err.max()))
-        n_over += int((err > 1e-4).sum())
+        err = np.abs(gpu_images[v] - st.image).max(0)
+        amb = R.ambiguity_mask(st) != 0     # pixels sitting on alpha = 1/255 or T = 1e-4
+        linf_all = max(linf_all, float(err.max()))
+        linf_ok = max(linf_ok, float(err[~amb].max()))
+        n_over += int((err[~amb] > 1e-4).sum())
+        n_marked += int(amb.sum())
         n_pix += err.size
         mse.append(float((diff ** 2).mean()))
     R.parallel_backward(False)
@@ -130,11 +133,13 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
                 sample=f"first {n_views} of {tgt.near.numel()} views of the step (scene-major), "
                        f"{hw[0]}x{hw[1]}, G={gaussians.means.shape[1]}, fwd+bwd, "
                        f"oracle/raster_ref.c with OpenMP on {cores} threads, {t_total:.1f} s"), \
-        dict(linf=linf, psnr_db=psnr if psnr != float("inf") else 999.0,
-             values_compared=n_pix, values_over_1e_4=n_over,
-             note="values over 1e-4 are alpha >= 1/255 / T < 1e-4 threshold flips (fp32 exp "
-                  "rounding differs between v_exp_f32 and libm); each is bounded by one "
-                  "minimum-alpha contribution, ~4e-3")
+        dict(linf=linf_ok, psnr_db=psnr if psnr != float("inf") else 999.0,
+             pixels_compared=n_pix, pixels_over_1e_4=n_over, pixels_on_a_threshold=n_marked,
+             linf_including_threshold_pixels=linf_all,
+             note="linf / pixels_over_1e_4 are over the pixels that do not sit on one of the blend's "
+                  "hard thresholds (oracle.raster_ref.ambiguity_mask: alpha within 3e-6 of 1/255, "
+                  "T(1-alpha) within 3e-6 of 1e-4); on those a last-bit difference of exp() flips a "
+                  "branch and adds or removes one minimum-alpha contribution; PSNR is over all pixels")
 
 
 def cpu_baseline_epipolar(et, feat_nhwc, ctx, num_samples, heads):

@@ -164,16 +164,19 @@ def forward(means, cov6, opacity, view, proj, campos, bg, H, W, tanfovx, tanfovy
                         image, final_T, n_contrib)
 
 
-def ambiguity_mask(st: ForwardState, tol_alpha: float = 2e-5, tol_T: float = 1e-4,
-                   tol_power: float = 1e-5) -> np.ndarray:
+def ambiguity_mask(st: ForwardState, tol_alpha: float = 3e-6, tol_T: float = 3e-6,
+                   tol_power: float = 1e-7) -> np.ndarray:
     """uint8 [H, W]: pixels whose forward walk evaluates an entry sitting on one of the blend's
     hard thresholds (bit 0: alpha ~ alpha_min, bit 1: T (1 - alpha) ~ t_min, bit 2: power ~ 0)
     within the given relative tolerances -- there two correct fp32 implementations may branch
     differently (see ps_oracle_blend_ambiguity in raster_ref_impl.inc).
 
-    Defaults: an fp32 evaluation of `power` (|terms| up to ~10, three roundings, the
-    log2(e)-scaled coefficients of the HIP kernel) is off by a few 1e-6 absolute = the
-    relative error of alpha; T is a product of up to a few hundred (1 - alpha) factors."""
+    Defaults: measured on MI355X (tools/ambiguity_sweep.py, profiles/r2_ambiguity_sweep.txt):
+    at BASELINE configs[1] and [4] every pixel over 1e-4 (up to 1.2e-3: one minimum-alpha
+    contribution) disappears from the unmarked set at tol_alpha = tol_T = 1e-6 -- an fp32
+    evaluation of `power` with the HIP kernel's log2(e)-scaled coefficients and v_exp_f32 is
+    off by a few 1e-7 relative in alpha -- and the worst unmarked error is then 4.8e-7.  The
+    defaults keep a 3x margin over that and mark ~0.05 % of the pixels."""
     L = lib()
     dtype = st.dtype
     suf = "_f32" if dtype == np.float32 else "_f64"

@@ -9,15 +9,15 @@ not computed by the product's camera kernel -- which is separately held to them.
 Bars (BASELINE.json north_star):
   * bit-exact: radii, per-tile counts, every sorted per-tile list;
   * image, final_T: L_inf <= 1e-4 on EVERY pixel whose blend does not sit on a hard threshold
-    (oracle.raster_ref.ambiguity_mask: an entry within 2e-5 relative of alpha = 1/255, within
-    1e-4 relative of T (1 - alpha) = 1e-4, or |power| < 1e-5).  Two fp32 implementations
-    whose exp() differs in the last bit may branch differently there; a flip is one whole
-    minimum-alpha contribution, not a rounding error.  The marked fraction is asserted small
-    (< 1 %) and printed;
+    (oracle.raster_ref.ambiguity_mask: an entry within 3e-6 relative of alpha = 1/255 or of
+    T (1 - alpha) = 1e-4, or |power| < 1e-7; tolerances from tools/ambiguity_sweep.py on
+    MI355X).  Two fp32 implementations whose exp() differs in the last bit may branch
+    differently there; a flip is one whole minimum-alpha contribution, not a rounding error.
+    The marked fraction is asserted small (< 0.2 %) and printed;
   * n_contrib: equal on every unmarked pixel;
   * gradients (means, covariances, harmonics, opacities), dL/dimage zeroed on the marked pixels:
-    within 1e-3 of the per-tensor max (fp32 sums in different orders on both sides; the oracle's
-    backward runs tile-parallel with atomics here).
+    within 5e-5 of the per-tensor max (fp32 sums in different orders on both sides; the oracle's
+    backward runs tile-parallel with atomics here; measured 1e-6 .. 2e-6).
 """
 import numpy as np
 import pytest
@@ -29,7 +29,7 @@ from tests.cases import make_workload, oracle_view_inputs, reference_cameras
 pytestmark = pytest.mark.gpu
 
 IMG_TOL = 1e-4
-GRAD_TOL = 1e-3
+GRAD_TOL = 5e-5
 
 
 def _run_config(name, dev, gemm_note=None):
@@ -90,7 +90,7 @@ def _run_config(name, dev, gemm_note=None):
         assert np.array_equal(ncontrib[vi][ok], st.n_contrib.reshape(hw)[ok].astype(np.int32)), \
             (name, vi, int((ncontrib[vi][ok] != st.n_contrib.reshape(hw)[ok]).sum()))
         dL[vi][:, amb] = 0.0
-    assert stats["marked"] < 0.01 * stats["pixels"], stats
+    assert stats["marked"] < 0.002 * stats["pixels"], stats
 
     # backward: every gradient tensor against the oracle, summed over the views of the scene
     (img_t * torch.from_numpy(dL).to(dev)).sum().backward()
