@@ -31,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# (size, batch, target views, context views) -> which BASELINE.json config the run is
+BASELINE_TAG = {(256, 7, 4, 2): " (BASELINE.json configs[1])", (64, 1, 4, 2): " (BASELINE.json configs[0])",
+                (256, 4, 4, 3): " (BASELINE.json configs[3])", (512, 2, 4, 2): " (BASELINE.json configs[4])"}
 
 
 def parse():
@@ -41,6 +44,8 @@ def parse():
     p.add_argument("--batch", type=int, default=7)
     p.add_argument("--size", type=int, default=256)
     p.add_argument("--views", type=int, default=4, help="target views per scene")
+    p.add_argument("--context-views", type=int, default=2,
+                   help="context views per scene (3: BASELINE configs[3], acid 3-view)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--grad-payload-mb", type=float, default=0.0,
                    help="N > 1: extra synthetic fp32 gradient payload all-reduced per step, to model "
@@ -197,7 +202,8 @@ def main():
     tuned_gemms = (not os.environ.get("PIXELSPLAT_NO_TUNED_GEMMS")) and gemm_tuning.enable()
     hw = (args.size, args.size)
     b, v = args.batch, args.views
-    ctx, tgt, g, target = make_workload(b, hw, v_ctx=2, v_tgt=v, seed=P.rank_seed(0, rank))
+    vc = args.context_views
+    ctx, tgt, g, target = make_workload(b, hw, v_ctx=vc, v_tgt=v, seed=P.rank_seed(0, rank))
     G = g.means.shape[1]
     V = b * v
 
@@ -223,23 +229,25 @@ def main():
         self_attention=ImageSelfAttentionCfg(patch_size=4, num_octaves=10, num_layers=2,
                                              num_heads=4, d_token=128, d_dot=128, d_mlp=256),
         num_octaves=10, num_layers=2, num_heads=heads, num_samples=n_samp, d_dot=128, d_mlp=256,
-        downscale=down), d_feat, num_context_views=2).to(dev)
+        downscale=down), d_feat, num_context_views=vc).to(dev)
     hA, wA = hw[0] // down, hw[1] // down
     torch.manual_seed(P.rank_seed(0, rank))
-    feat = torch.randn(b, 2, hA, wA, d_feat, device=dev).requires_grad_(True)   # channels-last
+    feat = torch.randn(b, vc, hA, wA, d_feat, device=dev).requires_grad_(True)   # channels-last
+    view_shuffle = torch.randperm(vc - 1, device=dev) if vc > 2 else None
     c_ext, c_intr = ctx.extrinsics.to(dev), ctx.intrinsics.to(dev)
     c_near, c_far = ctx.near.to(dev), ctx.far.to(dev)
     a_params = [p_ for n_, p_ in et.named_parameters()
-                if n_.startswith(("transformer.layers", "depth_encoding"))
+                if n_.startswith(("transformer.layers", "depth_encoding", "view_embeddings"))
                 and "self_attention" not in n_]
 
     def path_a():
         geo = et.epipolar_sampler.geometry(c_ext, c_intr, c_near, c_far, (hA, wA))
         x = feat.reshape(-1, 1, d_feat)
-        folds = et.fold_layers()
+        view_emb = et.view_embeddings(view_shuffle) if vc > 2 else None  # epipolar_transformer.py:126-131
+        folds = et.fold_layers(view_emb)
         grad_batch = FeatureGradBatch()
         for (attn, _ff), folded in zip(et.transformer.layers, folds):
-            x = et.fused_block(attn, x, feat, geo, folded=folded, batch=grad_batch)
+            x = et.fused_block(attn, x, feat, geo, view_emb=view_emb, folded=folded, batch=grad_batch)
         return x.square().mean()
 
     def path_b():
@@ -272,10 +280,10 @@ def main():
     ga = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 4)).to(dev)
     n_rays = hw[0] * hw[1]
     ga_in = dict(
-        coordinates=torch.rand(b, 2, n_rays, 1, 1, 2, device=dev).requires_grad_(True),
-        depths=(torch.rand(b, 2, n_rays, 1, 3, device=dev) * 5 + 0.5).requires_grad_(True),
-        opacities=torch.rand(b, 2, n_rays, 1, 3, device=dev),
-        raw=torch.randn(b, 2, n_rays, 1, 1, 82, device=dev).requires_grad_(True))
+        coordinates=torch.rand(b, vc, n_rays, 1, 1, 2, device=dev).requires_grad_(True),
+        depths=(torch.rand(b, vc, n_rays, 1, 3, device=dev) * 5 + 0.5).requires_grad_(True),
+        opacities=torch.rand(b, vc, n_rays, 1, 3, device=dev),
+        raw=torch.randn(b, vc, n_rays, 1, 1, 82, device=dev).requires_grad_(True))
     ga_ext, ga_intr = c_ext[:, :, None, None, None], c_intr[:, :, None, None, None]
 
     def step_adapter():
@@ -288,9 +296,9 @@ def main():
     # ---- depth predictor: ReLU + Linear + the fused sampler, same rays
     from pixelsplat_amd.encoder import DepthPredictorMonocular
     dp = DepthPredictorMonocular(d_feat, 32, 1, False).to(dev)
-    dp_feat = torch.randn(b, 2, n_rays, d_feat, device=dev).requires_grad_(True)
-    dp_near = torch.full((b, 2), 1.0, device=dev)
-    dp_far = torch.full((b, 2), 100.0, device=dev)
+    dp_feat = torch.randn(b, vc, n_rays, d_feat, device=dev).requires_grad_(True)
+    dp_near = torch.full((b, vc), 1.0, device=dev)
+    dp_far = torch.full((b, vc), 100.0, device=dev)
 
     def step_depth():
         dp_feat.grad = None
@@ -310,7 +318,7 @@ def main():
         gaussians_per_pixel=3, gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 4),
         opacity_mapping=OpacityMappingCfg(0.0, 0.0, 1), use_transmittance=False)).to(dev)
     head_ctx = dict(extrinsics=c_ext, intrinsics=c_intr, near=ctx.near.to(dev), far=ctx.far.to(dev))
-    head_feat = torch.randn(b, 2, *hw, d_feat, device=dev).permute(0, 1, 4, 2, 3).requires_grad_(True)
+    head_feat = torch.randn(b, vc, *hw, d_feat, device=dev).permute(0, 1, 4, 2, 3).requires_grad_(True)
 
     def step_chain():
         head_feat.grad = None
@@ -395,8 +403,8 @@ def main():
         }
         # (A): compulsory HBM bytes of the folded formulation per launch; these
         # kernels are VALU/latency bound, the figures are there to show how far from HBM
-        RA, TA, PA = b * 2 * hA * wA, n_samp, 20
-        fm = 4.0 * b * 2 * hA * wA * d_feat
+        RA, TA, PA = b * vc * hA * wA, n_samp * (vc - 1), 20
+        fm = 4.0 * b * vc * hA * wA * d_feat
         alg.update({
             "epipolar_geometry": RA * (24.0 + 25.0 + 16.0 * TA),
             "epipolar_attention_forward": fm + RA * (12.0 * TA + 4.0 * heads * (2 * d_feat + 2 * PA + TA)),
@@ -414,11 +422,12 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"re10k 2-view, {hw[0]}x{hw[1]}, batch_size={b} per GPU, {v} target "
-                            f"views/scene{' (BASELINE.json configs[1])' if (hw[0], b, v) == (256, 7, 4) else ''}: epipolar sampler + 2 "
-                            f"cross-attention layers on [{b},2,{d_feat},{hA},{wA}] (A) + "
+                "workload": f"{'acid' if vc > 2 else 're10k'} {vc}-view, {hw[0]}x{hw[1]}, batch_size={b} per GPU, {v} target "
+                            f"views/scene{BASELINE_TAG.get((hw[0], b, v, vc), '')}: epipolar sampler + 2 "
+                            f"cross-attention layers on [{b},{vc},{d_feat},{hA},{wA}] (A) + "
                             f"rasterizer (B), fwd+bwd",
-                "epipolar_rays": b * 2 * hA * wA, "epipolar_samples_per_ray": n_samp,
+                "epipolar_rays": b * vc * hA * wA, "epipolar_samples_per_ray": n_samp,
+                "epipolar_kv_tokens_per_ray": n_samp * (vc - 1),
                 "gaussians_per_scene": G, "views_per_step_per_gpu": V,
                 "tile_list_entries_D": D_total, "visible_gaussian_views": n_visible,
                 "D_over_GV": round(D_total / (G * V), 3), "parallelism": f"dp{world}",
