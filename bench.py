@@ -51,6 +51,9 @@ def parse():
                    help="N > 1: extra synthetic fp32 gradient payload all-reduced per step, to model "
                         "the rest of the network (the reference reduces ~480 MB; SURVEY.md 5)")
     p.add_argument("--bucket-mb", type=float, default=25.0, help="gradient bucket size (torch DDP default)")
+    p.add_argument("--launch", choices=["graph", "eager"], default="graph",
+                   help="graph: the step is replayed from two hipGraphs ((A) fwd+bwd, (B) fwd+bwd; "
+                        "fixed-capacity tile lists, no host sync); eager: launch by launch")
     p.add_argument("--cpu-views", type=int, default=16, help="views in the CPU-baseline sample")
     return p.parse_args()
 
@@ -250,8 +253,11 @@ def main():
             x = et.fused_block(attn, x, feat, geo, view_emb=view_emb, folded=folded, batch=grad_batch)
         return x.square().mean()
 
+    list_cap = [0]     # > 0: fixed-capacity tile lists (no host sync in the forward)
+
     def path_b():
-        img = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v)
+        img = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v,
+                          list_capacity=list_cap[0])
         return mse_loss(img, tgt_img, 1.0)   # LossMse (loss_mse.py:30-31), one pass
 
     def zero_grads():
@@ -263,7 +269,41 @@ def main():
     reducer = P.GradientReducer(a_params, world, bucket_bytes=int(args.bucket_mb * (1 << 20)),
                                 extra_payload_bytes=int(args.grad_payload_mb * 1e6))
 
+    graphs = {}
+
+    def capture_graphs():
+        """The step as two hipGraphs -- (A) forward + backward, (B) forward + backward -- sharing
+        one memory pool.  ~95 launches of (A) and ~30 of (B) become two graph launches: no
+        per-launch host cost, no allocator traffic, no host synchronisation (fixed-capacity tile
+        lists; an overflow is read back after the replay).  The gradient all-reduce is launched
+        between the two replays, so it runs under (B) exactly as in the eager schedule."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # eager warm-up in the mode that will be captured
+            for _ in range(2):
+                zero_grads()
+                path_a().backward()
+                path_b().backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        zero_grads()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            path_a().backward()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            path_b().backward()
+        graphs["a"], graphs["b"] = ga, gb
+
     def step(a=True, b_=True):
+        if graphs:
+            if a:
+                graphs["a"].replay()
+                reducer.reduce_now()
+                reducer.launch_extra_payload()
+            if b_:
+                graphs["b"].replay()
+            reducer.finish()
+            return
         zero_grads()
         la = path_a() if a else None
         lb = path_b() if b_ else None
@@ -348,21 +388,55 @@ def main():
     del aux, counts, img
     torch.cuda.empty_cache()
 
+    launch_mode = "eager"
+    if args.launch == "graph":
+        from pixelsplat_amd.raster import captured_overflow_flags
+        list_cap[0] = (int(D_total * 1.25) + 4095) // 4096 * 4096
+        try:
+            capture_graphs()
+            step()
+            torch.cuda.synchronize()
+            captured_overflow_flags(check=True)
+            launch_mode = "hipgraph"
+        except Exception as err:       # capture not possible in this build: the eager schedule
+            print(f"[bench] hipGraph capture failed ({type(err).__name__}: {err}); "
+                  f"falling back to eager launches", file=sys.stderr)
+            graphs.clear()
+            list_cap[0] = 0
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     ng = lib.ps_profile_group_count()
     tot_ms = (C.c_double * ng)()
     launches = (C.c_int64 * ng)()
     P.barrier(world)
-    lib.ps_profile_enable(1)
+    if launch_mode == "eager":
+        lib.ps_profile_enable(1)       # HIP events around every library launch of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     P.barrier(world)
     elapsed = time.perf_counter() - t0
     lib.ps_profile_enable(0)
-    _lib.check(lib.ps_profile_collect(tot_ms, launches), "ps_profile_collect")
     elapsed = P.max_over_ranks(elapsed, world, dev)
+    if launch_mode == "hipgraph":
+        # events cannot be read from inside a replayed graph: the same kernels are timed in an
+        # eager pass of the same K steps right after the timed region (same process, same data)
+        captured_overflow_flags(check=True)
+        saved = dict(graphs)
+        static_grads = [(t, t.grad) for t in (means, cov, sh, op, feat, *a_params)]
+        graphs.clear()
+        step()
+        torch.cuda.synchronize()
+        lib.ps_profile_enable(1)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        lib.ps_profile_enable(0)
+        graphs.update(saved)
+        for t, g_ in static_grads:      # the graphs write into these tensors
+            t.grad = g_
+    _lib.check(lib.ps_profile_collect(tot_ms, launches), "ps_profile_collect")
     # outside the contract's timed region: each path alone
     ms_b = timed(lambda: step(a=False), args.steps)
     ms_a = timed(lambda: step(b_=False), args.steps)
@@ -437,6 +511,10 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "avg_kernel_ms": round(dom_ms, 4),
+                "kernel_timing": ("HIP events around the kernel's launches over the timed steps"
+                                  if launch_mode == "eager" else
+                                  "HIP events over an eager pass of the same K steps right after the "
+                                  "timed region (the timed region replays the same kernels from hipGraphs)"),
                 # the dominant kernel is VALU-issue bound, not HBM bound: share of
                 # its time the SIMDs spend issuing VALU instructions, from the committed PMC run
                 "valu_issue_frac": (round(valu_ms / dom_ms, 3) if valu_ms else None),
@@ -452,6 +530,7 @@ def main():
                                          if pmc_valu_busy_ms(g_) else None)}
                 for g_ in SINGLE_KERNEL_GROUPS
                 if g_ in groups and groups[g_][0] > 0 and pmc_traffic(g_)[0]},
+            "launch": launch_mode,
             "library_gemm_table": ("pixelsplat_amd/gemm_tuning/gfx950_rocm7_torch2.10.csv"
                                    if tuned_gemms else None),
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},

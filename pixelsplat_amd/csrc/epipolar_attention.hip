@@ -912,8 +912,8 @@ int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const fl
   const size_t sm = attn_smem(dm);
 #define PS_GO(L)                                                                                \
   do {                                                                                          \
-    (void)hipFuncSetAttribute((const void*)epipolar_attn_forward_kernel<L>,                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
+    static const bool lds_ok_ = (hipFuncSetAttribute((const void*)epipolar_attn_forward_kernel<L>,                \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;             \
     hipLaunchKernelGGL(epipolar_attn_forward_kernel<L>, grid, block, sm, st, dm, fmap, xy,      \
                        flags, rd, qt, u, e, scale, fbar, pbar, abar, attn);                     \
   } while (0)
@@ -934,8 +934,8 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
   const size_t sm = attn_smem(dm);
 #define PS_GO(L)                                                                                \
   do {                                                                                          \
-    (void)hipFuncSetAttribute((const void*)epipolar_attn_backward_kernel<L>,                    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
+    static const bool lds_ok_ = (hipFuncSetAttribute((const void*)epipolar_attn_backward_kernel<L>,                \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;             \
     hipLaunchKernelGGL(epipolar_attn_backward_kernel<L>, grid, block, sm, st, dm, fmap, xy,     \
                        flags, rd, attn, fbar, pbar, abar, dfbar, dpbar, dabar, scale, dqt, du,  \
                        de, ds);                                                                 \

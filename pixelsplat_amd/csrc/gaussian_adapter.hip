@@ -531,8 +531,8 @@ int launch_adapter_forward(int n_views, int rp, int spp, int sh_degree, float sm
   const size_t sm = adapter_lds(sh_degree, spp, skip);
 #define PS_GO2(D, SK)                                                                         \
   do {                                                                                        \
-    (void)hipFuncSetAttribute((const void*)adapter_forward_kernel<D, SK>,                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);           \
+    static const bool lds_ok_ = (hipFuncSetAttribute((const void*)adapter_forward_kernel<D, SK>,\
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;           \
     hipLaunchKernelGGL((adapter_forward_kernel<D, SK>), grid, block, sm, st, dm, smin, smax,  \
                        eps, views, coords, depths, raw, means, cov, harmonics);               \
   } while (0)
@@ -560,8 +560,8 @@ int launch_adapter_backward(int n_views, int rp, int spp, int sh_degree, float s
   const size_t sm = adapter_lds(sh_degree, spp, skip);
 #define PS_GO2(D, SK)                                                                         \
   do {                                                                                        \
-    (void)hipFuncSetAttribute((const void*)adapter_backward_kernel<D, SK>,                    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);           \
+    static const bool lds_ok_ = (hipFuncSetAttribute((const void*)adapter_backward_kernel<D, SK>,\
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;           \
     hipLaunchKernelGGL((adapter_backward_kernel<D, SK>), grid, block, sm, st, dm, smin, smax, \
                        eps, views, coords, depths, raw, d_means, d_cov, d_harmonics, d_raw,   \
                        d_depths, d_coords);                                                   \

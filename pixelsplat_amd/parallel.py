@@ -205,6 +205,24 @@ class GradientReducer:
         if b["pending"] == 0:
             self._launch(b)
 
+    def reduce_now(self) -> None:
+        """Hook-free variant for steps replayed from hipGraphs (the gradients are static tensors
+        written by the graph, no accumulate hook fires): copies every gradient into its bucket
+        and launches the buckets' all-reduces asynchronously.  `finish()` waits and copies the
+        means back into the gradient tensors.  Parameters without a gradient count as zero."""
+        if self.world <= 1 or not self.params:
+            return
+        for b in self.buckets:
+            for slot, (p, view) in enumerate(zip(b["params"], b["views"])):
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                b["ready"][slot] = p.grad is not None
+            b["pending"] = 0
+            b["copy_back"] = True
+            self._launch(b)
+
     def launch_extra_payload(self) -> None:
         """All-reduce of the synthetic payload (the rest of the network's gradients), in
         bucket-sized pieces, asynchronously; call where that backward would run."""
@@ -232,6 +250,10 @@ class GradientReducer:
             w.wait()
         self._works.clear()
         for b in self.buckets:
+            if b.pop("copy_back", False):      # reduce_now(): static gradient tensors keep their
+                for p, view in zip(b["params"], b["views"]):   # storage, the mean is copied back
+                    if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                        p.grad.copy_(view)
             # a parameter unused on THIS rank still receives the other ranks' mean gradient
             for p, view, ok in zip(b["params"], b["views"], b["ready"]):
                 if not ok:

@@ -111,8 +111,8 @@ class ForwardResult:
         """Fixed-capacity mode: waits for the forward's 8-byte flag copy and raises when the
         tile lists did not fit (the image was then blended from truncated lists).  No-op in
         exact-sizing mode."""
-        if self.overflow_host is None:
-            return
+        if self.overflow_host is None or self.overflow_event is None:
+            return   # exact sizing, or recorded into a hipGraph (see captured_overflow_flags)
         self.overflow_event.synchronize()
         if int(self.overflow_host[1]) != 0:
             raise RuntimeError(
@@ -145,11 +145,17 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
             temp.numel(), _p(plist), plist.numel(), _stream()), "ps_raster_forward_tiles")
         lay = _lib.PsRasterStateLayout()
         lib.ps_raster_state_layout(C.byref(d), C.byref(lay))
-        flag = torch.empty(2, dtype=torch.int32, pin_memory=True)  # caching host allocator
+        flag = _pinned_flag()
         flag.copy_(state[lay.num_rendered:lay.num_rendered + 8].view(torch.int32),
                    non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = None
+        if torch.cuda.is_current_stream_capturing():
+            # hipGraph capture: no host wait may be recorded.  The copy is a node of the graph;
+            # the caller checks `captured_overflow_flags()` after a replay has completed.
+            _CAPTURED_FLAGS.append((flag, cfg.list_capacity))
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
         return ForwardResult(color, radii, state, plist, None, flag, ev, bwd_temp)
     # exact sizing: D is read back once per batch.  The SH colours are deferred behind that
     # copy, so the GPU evaluates them while the host waits for D, allocates and launches.
@@ -187,6 +193,38 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
 
 
 _SIDE_STREAMS: dict = {}
+_PINNED_FLAGS: list = []      # pinned [2] int32 buffers of the fixed-capacity mode, recycled
+_PINNED_NEXT = [0]
+_CAPTURED_FLAGS: list = []    # (flag, capacity) of forwards recorded into a hipGraph
+
+
+def _pinned_flag() -> Tensor:
+    """A pinned 8-byte landing buffer for (D, overflow).  Pinned allocations are not allowed while
+    a stream is being captured, so the buffers of the eager warm-up steps are kept and handed out
+    round-robin (one per rasterize call of a step)."""
+    if torch.cuda.is_current_stream_capturing():
+        if not _PINNED_FLAGS:
+            raise RuntimeError("pixelsplat_amd.rasterize under hipGraph capture: run one eager "
+                               "(warm-up) step with the same list_capacity first")
+        _PINNED_NEXT[0] = (_PINNED_NEXT[0] + 1) % len(_PINNED_FLAGS)
+        return _PINNED_FLAGS[_PINNED_NEXT[0]]
+    if len(_PINNED_FLAGS) < 16:
+        _PINNED_FLAGS.append(torch.empty(2, dtype=torch.int32, pin_memory=True))
+        return _PINNED_FLAGS[-1]
+    return torch.empty(2, dtype=torch.int32, pin_memory=True)   # caching host allocator
+
+
+def captured_overflow_flags(check: bool = True) -> list:
+    """Fixed-capacity forwards recorded into a hipGraph cannot raise from inside the graph: after
+    a replay has completed (synchronise first) this returns [(entries needed, overflowed?,
+    capacity)] per recorded forward and, with `check`, raises if any list did not fit."""
+    out = [(int(f[0]), bool(int(f[1])), cap) for f, cap in _CAPTURED_FLAGS]
+    if check:
+        for need, over, cap in out:
+            if over:
+                raise RuntimeError(f"pixelsplat_amd.rasterize (hipGraph replay): {need} tile-list "
+                                   f"entries exceed list_capacity={cap} (PS_ERR_CAPACITY)")
+    return out
 
 
 def _zeroed_backward_temp(cfg: "RasterConfig", capacity: int, dev):
