@@ -190,6 +190,18 @@ def ambiguity_mask(st: ForwardState, tol_alpha: float = 3e-6, tol_T: float = 3e-
     return mask.reshape(P.H, P.W)
 
 
+def blend_stats(st: ForwardState) -> tuple[int, int]:
+    """((pixel, entry) pairs the reference walk evaluates, pairs that contribute)."""
+    L = lib()
+    suf = "_f32" if st.dtype == np.float32 else "_f64"
+    out = np.zeros(2, np.int64)
+    pl = st.point_list if st.num_rendered else np.zeros(1, np.uint32)
+    getattr(L, "ps_oracle_blend_stats" + suf)(
+        C.byref(st.params), _ptr(st.ranges), _ptr(pl), _ptr(st.xy), _ptr(st.conic_opacity),
+        _ptr(out))
+    return int(out[0]), int(out[1])
+
+
 def backward(st: ForwardState, dL_dimage):
     """Returns dict(means3D, means2D, cov6, sh|colors, opacity) -- the five gradients the
     reference's autograd needs (SURVEY.md section 8b 'Gradients required')."""

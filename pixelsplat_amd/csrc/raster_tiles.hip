@@ -114,6 +114,17 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, f
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// VAR 0: the round-1 inner loop (explicitly rotated LDS prefetch, `live` flags, termination test
+// after every entry).  VAR 1 (default): fewer wave instructions per (pixel, entry) pair --
+//   * the transmittance carries the "finished" state in its sign (T > 0: live, T < 0: the pixel
+//     stopped and -T is its final value), so there is no separate flag to test, mask and update;
+//   * power and the (T (1 - a), T a) pair are written on 2-vectors -> v_pk_add / v_pk_mul;
+//   * the record of entry j is read from LDS where it is used (the other waves of the SIMD cover
+//     the latency) instead of being prefetched into a second register set and moved;
+//   * "is every pixel finished?" is asked once per 8 entries, not per entry.
+template <int VAR>
 __global__ void __launch_bounds__(kWavesPerBlock* kWave)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ tile_order,
@@ -219,12 +230,58 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     wave_lds_sync();
   };
 
+  // VAR 1: Ts[k] = T while the pixel is live, -T once it has stopped (pixels outside the image
+  // start stopped); T[] / live[] above are unused then
+  float Ts[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) Ts[k] = live[k] ? 1.f : -1.f;
+  auto blend1 = [&](uint32_t m) {
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t slot = (b_head + j) & (kQB - 1);
+      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const uint32_t hidx = __float_as_uint(q2.y);
+      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
+          const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
+          const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
+          const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
+          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+          const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
+          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+          float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
+          asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
+          const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
+          const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
+          const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
+          Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
+          C0[k] = fmaf(q1.z, wgt, C0[k]);
+          C1[k] = fmaf(q1.w, wgt, C1[k]);
+          C2[k] = fmaf(q2.x, wgt, C2[k]);
+          last[k] = (ok & !stop) ? hidx : last[k];
+        }
+      }
+      if ((j & 7u) == 7u &&
+          !__any((Ts[0] > 0.f) | (Ts[1] > 0.f) | (Ts[2] > 0.f) | (Ts[3] > 0.f))) {
+        all_done = true;
+        break;
+      }
+    }
+    b_head += m;
+    wave_lds_sync();
+  };
+
   for (uint32_t first = 0; first < l_count && !all_done; first += kBatch) {
     const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
     refine(first, m);
-    while (!all_done && b_tail - b_head >= (uint32_t)kBatch) blend(kBatch);
+    while (!all_done && b_tail - b_head >= (uint32_t)kBatch) { if (VAR == 0) blend(kBatch); else blend1(kBatch); }
   }
-  if (!all_done && b_tail != b_head) blend(b_tail - b_head);
+  if (!all_done && b_tail != b_head) { if (VAR == 0) blend(b_tail - b_head); else blend1(b_tail - b_head); }
+  if (VAR != 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T[k] = fabsf(Ts[k]);
+  }
 
   // epilogue
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
@@ -257,8 +314,13 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                     point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
+  static const int variant = [] { const char* e = getenv("PS_TILES_FWD_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant == 0)
+    hipLaunchKernelGGL(tiles_forward_kernel<0>, grid, block, 0, st, d, records, tile_order, tile_ranges,
+                       point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
+  else
+    hipLaunchKernelGGL(tiles_forward_kernel<1>, grid, block, 0, st, d, records, tile_order, tile_ranges,
+                       point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
 }
 
 // ------------------------------------------------------------------------------------
@@ -307,6 +369,9 @@ __device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float 
       : "+v"(r1), "+v"(r2), "+v"(i));
 }
 
+// VAR 0: round-1 loop (LDS prefetch rotated through a second register set); VAR 1: the record of
+// entry j is read where it is used, (dx, dy) / (B dy, C dy) as 2-vectors.
+template <int VAR>
 __global__ void __launch_bounds__(kWavesPerBlock* kWave, 4)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ tile_order,
@@ -424,10 +489,14 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
            n2 = lds.rec[b_head & (kQB - 1)][2];
     for (uint32_t j = 0; j < m; ++j) {
-      const float4 q0 = n0, q1 = n1, q2 = n2;
-      {
+      float4 q0, q1, q2;
+      if (VAR == 0) {
+        q0 = n0; q1 = n1; q2 = n2;
         const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
         n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
+      } else {
+        const uint32_t slot = (b_head + j) & (kQB - 1);
+        q0 = lds.rec[slot][0]; q1 = lds.rec[slot][1]; q2 = lds.rec[slot][2];
       }
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
@@ -438,8 +507,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (qm & (1u << k)) {   // wave-uniform quadrant skip
-          const float dx = q0.x - pxf[k], dy = q0.y - pyf[k];
-          const float pw = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), q1.x * dy * dy);
+          const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};
+          const float dx = dd.x, dy = dd.y;
+          const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dy, dy};          // (B dy, C dy)
+          const float pw = fmaf(dx, fmaf(q0.z, dx, bc.x), dy * bc.y);
           const float Gv = fast_exp2(pw);
           const float alpha = fminf(alpha_max, o * Gv);
           const bool ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
@@ -530,10 +601,15 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order,
-                     tile_ranges,
-                     point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
-                     grad2d, tile_grads);
+  static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant == 0)
+    hipLaunchKernelGGL(tiles_backward_kernel<0>, grid, block, 0, st, d, records, tile_order,
+                       tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end,
+                       dL_dcolor, grad2d, tile_grads);
+  else
+    hipLaunchKernelGGL(tiles_backward_kernel<1>, grid, block, 0, st, d, records, tile_order,
+                       tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end,
+                       dL_dcolor, grad2d, tile_grads);
 }
 
 }  // namespace ps
