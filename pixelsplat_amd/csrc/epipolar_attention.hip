@@ -868,6 +868,240 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
 }
 
 // ------------------------------------------------------------------------------------
+// Two-pass variant of the feature-map gradient.
+//
+// The single-pass kernel above reloads a ray's 16 coefficient rows (dfbar_h, q~_h of both layers:
+// 8 KB at c = 128) and the coefficients of all its samples (4.6 KB) for EVERY tile its line
+// crosses (~10 tiles): 14 GB of L2-level reads and 4.7 GB on the memory side per launch at the
+// paper config for 0.47 GB of rows, and 80 wave instructions per (token, tile) visit of which
+// 48 rebuild the token's gradient vector from the rows.
+//   pass 1 (token_grad_kernel): one wave per (ray, other view) builds, ONCE per token,
+//       g_t[c] = sum over layers, heads of a_t dfbar[c] + ds_t q~[c]
+//     -- the gradient w.r.t. the gathered feature of that token -- and streams it out
+//     (b v ov r s c floats: what the reference's autograd holds as d(kv); 0.94 GB at the paper
+//     config, written and read once);
+//   pass 2 (dfmap_gather_kernel): the same tile-owner scatter as above, but a (ray, tile) item
+//     only loads the sample positions, and per token ONE 512-byte row of g_t: 34 instructions
+//     per (token, tile) visit, ~1.6 GB of reads.
+// Same fixed summation order per pixel (view, ray, sample, corner) => bit-reproducible; the
+// value differs from the single pass only by the association of the layer / head sum.
+// ------------------------------------------------------------------------------------
+template <int CPL, int NL>
+__global__ void __launch_bounds__(256)
+epipolar_token_grad_kernel(AttnDims dm, const uint8_t* __restrict__ flags, FgradLayers L,
+                           float* __restrict__ tg) {
+  using V = typename LaneVec<CPL>::type;
+  const int R = dm.h * dm.w, ovn = dm.v - 1, T = dm.s * ovn, H = dm.heads;
+  const size_t n_ro = (size_t)dm.b * dm.v * ovn * R;
+  const size_t ro = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (bv, ov, r)
+  if (ro >= n_ro) return;
+  if (!(flags[ro] & 1)) return;            // no overlap: every weight is zero, never read
+  const int lane = threadIdx.x & 63;
+  const int r = (int)(ro % R);
+  const int ov = (int)((ro / R) % ovn);
+  const size_t bv = ro / ((size_t)R * ovn);
+  const size_t ray = bv * R + r;
+  const int c0 = lane * CPL;
+  const bool lane_c = c0 < dm.c;
+  const int cl = lane_c ? c0 : 0;
+  float gq[NL][kMaxHeads][CPL], qq[NL][kMaxHeads][CPL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      const int hs = hh < H ? hh : 0;
+      load_cpl<CPL>(L.dfbar[l] + ray * dm.ld_f + hs * dm.hs_f + cl, gq[l][hh]);
+      load_cpl<CPL>(L.qt[l] + ray * dm.ld_q + hs * dm.hs_q + cl, qq[l][hh]);
+    }
+  for (int s0 = 0; s0 < dm.s; s0 += kWave) {
+    // lanes <-> samples: the coefficients of this (ray, other view)
+    const int si = min(s0 + lane, dm.s - 1);
+    float av[NL][kMaxHeads], dv[NL][kMaxHeads];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh) {
+        const size_t rowh = ray * H + (hh < H ? hh : 0);
+        const float a_ = L.attn[l][rowh * T + si * ovn + ov];
+        const float d_ = L.ds[l][rowh * T + si * ovn + ov];
+        av[l][hh] = hh < H ? a_ : 0.f;      // absent heads: zero coefficients, no branches below
+        dv[l][hh] = hh < H ? d_ : 0.f;
+      }
+    const int n = min(kWave, dm.s - s0);
+    for (int tl = 0; tl < n; ++tl) {        // lanes <-> channels
+      float df[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) df[i] = 0.f;
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int hh = 0; hh < kMaxHeads; ++hh) {
+          const float a = lane_bcast(av[l][hh], tl), d = lane_bcast(dv[l][hh], tl);
+#pragma unroll
+          for (int i = 0; i < CPL; ++i) df[i] = fmaf(a, gq[l][hh][i], fmaf(d, qq[l][hh][i], df[i]));
+        }
+      if (lane_c) {
+        V out;
+        float* f = reinterpret_cast<float*>(&out);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) f[i] = df[i];
+        *reinterpret_cast<V*>(tg + (ro * dm.s + s0 + tl) * dm.c + c0) = out;
+      }
+    }
+  }
+}
+
+constexpr int kDfTokGroup = 4;   // token rows in flight per wave in pass 2
+
+template <int CPL, int TS>
+__global__ void __launch_bounds__(kDfWaves* kWave)
+epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
+                             const uint32_t* __restrict__ boxes, const float* __restrict__ tg,
+                             float* __restrict__ dfmap) {
+  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][TS*TS pixels + dummy][c]
+  using V = typename LaneVec<CPL>::type;
+  const int R = dm.h * dm.w, ovn = dm.v - 1;
+  const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
+  const int per_xcd = (int)gridDim.x / 8;                       // XCD-aware order, as above
+  const int work = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+  if (work >= n_work) return;
+  const int tile_id = work % (tiles_x * tiles_y);
+  const int src_bv = work / (tiles_x * tiles_y);                // (b, source view)
+  const int b = src_bv / dm.v, sv = src_bv % dm.v;
+  const int tx0 = (tile_id % tiles_x) * TS, ty0 = (tile_id / tiles_x) * TS;
+  const int tx1 = min(tx0 + TS, dm.w) - 1, ty1 = min(ty0 + TS, dm.h) - 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c0 = lane * CPL;
+  const bool lane_c = c0 < dm.c;
+  const int cl = lane_c ? c0 : 0;
+  const int tile_floats = TS * TS * dm.c + max(dm.c, kWave * CPL);   // + dummy slots
+  float* tile = tiles + (size_t)wv * tile_floats;
+  float* lane_base = tile + (lane_c ? 0 : TS * TS * dm.c) + c0;
+  const int lane_mul = lane_c ? 1 : 0;
+  for (int i = lane; i < tile_floats; i += kWave) tile[i] = 0.f;
+  wave_lds_sync();
+  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * tile_floats) +
+                   (size_t)wv * (kDfChunk / kDfWaves);
+  const int ngroups = (dm.s + kWave - 1) / kWave;                // 1 when s <= 64
+
+  for (int v = 0; v < dm.v; ++v) {
+    if (v == sv) continue;
+    const int ov = sv < v ? sv : sv - 1;
+    const size_t bv = (size_t)b * dm.v + v;
+    const size_t ro0 = (bv * ovn + ov) * R;
+    for (int chunk0 = 0; chunk0 < R; chunk0 += kDfChunk) {
+      // 1. cull: lanes <-> rays (identical to the single-pass kernel)
+      int count = 0;
+      for (int r0 = chunk0 + wv * kWave; r0 < min(chunk0 + kDfChunk, R); r0 += kDfWaves * kWave) {
+        const int r = r0 + lane;
+        const uint32_t box = r < R ? boxes[ro0 + r] : 0x00FF00FFu;
+        const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
+        bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+        if (hit) {
+          const size_t so = (ro0 + r) * dm.s;
+          const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * so);
+          const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (so + dm.s - 1));
+          const Corner ca = corner_of(p0.x, p0.y, dm.w, dm.h), cb = corner_of(p1.x, p1.y, dm.w, dm.h);
+          const float ax = (float)ca.x0 + ca.wx, ay = (float)ca.y0 + ca.wy;
+          const float dx = (float)cb.x0 + cb.wx - ax, dy = (float)cb.y0 + cb.wy - ay;
+          const float xlo = (float)tx0 - 1.02f, xhi = (float)tx1 + 1.02f;
+          const float ylo = (float)ty0 - 1.02f, yhi = (float)ty1 + 1.02f;
+          float ta = 0.f, tb = 1.f;
+          auto clip = [&](float pp, float qq) {       // pp * t <= qq
+            if (pp == 0.f) { if (qq < 0.f) tb = -1.f; return; }
+            const float rr = qq / pp;
+            if (pp < 0.f) ta = fmaxf(ta, rr); else tb = fminf(tb, rr);
+          };
+          clip(-dx, ax - xlo); clip(dx, xhi - ax); clip(-dy, ay - ylo); clip(dy, yhi - ay);
+          hit = ta <= tb;
+        }
+        const uint64_t m = __ballot(hit);
+        if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)(r - chunk0);
+        count += __popcll(m);
+      }
+      wave_lds_sync();
+      if (count == 0) continue;
+      // 2. walk the list: sample positions one item ahead, token rows kDfTokGroup at a time (all
+      //    loads of a group issued before the first read-modify-write).  A deeper pipeline --
+      //    the next item's rows in flight during this item's LDS updates -- measured SLOWER
+      //    (0.69 -> 0.74 ms): the kernel is bound by issue + LDS, not by the row latency.
+      const int n_items = count * ngroups;
+      auto fetch_xy = [&](int item) {
+        const int rr = chunk0 + list[item / ngroups];
+        const int si = min((item % ngroups) * kWave + lane, dm.s - 1);
+        return *reinterpret_cast<const float2*>(xy + 2 * ((ro0 + rr) * dm.s + si));
+      };
+      float2 cur = fetch_xy(0);
+      for (int item = 0; item < n_items; ++item) {
+        const float2 nxt = fetch_xy(min(item + 1, n_items - 1));
+        const int rr = chunk0 + list[item / ngroups];
+        const int sbase = (item % ngroups) * kWave;
+        const bool tok = sbase + lane < dm.s;
+        const Corner kq = corner_of(cur.x, cur.y, dm.w, dm.h);
+        int off[4]; float wt[4]; bool any = false;
+#pragma unroll
+        for (int cr = 0; cr < 4; ++cr) {
+          const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
+          const bool in = tok && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
+          const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
+          off[cr] = (in ? (yy - ty0) * TS + (xx - tx0) : TS * TS) * dm.c;
+          wt[cr] = in ? wx * wy : 0.f;
+          any |= in;
+        }
+        uint64_t toks = __ballot(any);
+        const float* rows = tg + ((ro0 + rr) * dm.s + sbase) * (size_t)dm.c + cl;
+        while (toks) {
+          int tl[kDfTokGroup];
+          int n = 0;
+#pragma unroll
+          for (int q = 0; q < kDfTokGroup; ++q) {
+            tl[q] = toks ? __builtin_ctzll(toks) : 0;
+            if (toks) { toks &= toks - 1; ++n; }
+          }
+          float df[kDfTokGroup][CPL];
+#pragma unroll
+          for (int q = 0; q < kDfTokGroup; ++q)
+            if (q < n) load_cpl<CPL>(rows + (size_t)tl[q] * dm.c, df[q]);
+#pragma unroll
+          for (int q = 0; q < kDfTokGroup; ++q) {
+            if (q < n) {
+              V* dst[4]; V val[4];
+#pragma unroll
+              for (int cr = 0; cr < 4; ++cr) {
+                dst[cr] = reinterpret_cast<V*>(lane_base + lane_bcast_i(off[cr], tl[q]) * lane_mul);
+                val[cr] = *dst[cr];
+              }
+#pragma unroll
+              for (int cr = 0; cr < 4; ++cr) {
+                const float wgt = lane_bcast(wt[cr], tl[q]);
+                float* f = reinterpret_cast<float*>(&val[cr]);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[q][i], f[i]);
+                *dst[cr] = val[cr];
+              }
+            }
+          }
+        }
+        cur = nxt;
+      }
+      wave_lds_sync();
+    }
+  }
+  __syncthreads();
+  float* out = dfmap + (size_t)src_bv * R * dm.c;
+  const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+  for (int i = threadIdx.x; i < tw * th * dm.c; i += kDfWaves * kWave) {
+    const int pix = i / dm.c, ch = i - pix * dm.c;
+    const int py = pix / tw, px = pix - py * tw;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDfWaves; ++k)
+      acc += tiles[(size_t)k * tile_floats + (py * TS + px) * dm.c + ch];
+    out[((size_t)(ty0 + py) * dm.w + tx0 + px) * dm.c + ch] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 static size_t attn_smem(const AttnDims& dm) {
@@ -949,7 +1183,7 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
                                  const uint8_t* flags, const float* const* qt,
                                  const float* const* attn, const float* const* dfbar,
                                  const float* const* ds, float* dfmap, uint32_t* boxes,
-                                 hipStream_t st) {
+                                 float* token_grad, hipStream_t st) {
   if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
   if (n_layers < 1 || n_layers > kMaxFgradLayers) return PS_ERR_UNSUPPORTED;
   if (boxes == nullptr || dm.w > 255 || dm.h > 255) return PS_ERR_BAD_ARG;
@@ -969,6 +1203,21 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
   const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
   const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
   const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
+  if (token_grad != nullptr) {     // two passes: token gradients once, then the tile gather
+    dim3 g1((unsigned)((n_ro + 3) / 4)), b1(256);
+#define PS_TG(CPL)                                                                              \
+  do {                                                                                          \
+    if (n_layers == 1) hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 1>), g1, b1, 0, st,  \
+                                          dm, flags, L, token_grad);                            \
+    else hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 2>), g1, b1, 0, st, dm, flags, L,  \
+                            token_grad);                                                        \
+    hipLaunchKernelGGL((epipolar_dfmap_gather_kernel<CPL, TS>), g2, b2, sm2, st, dm, n_work,    \
+                       xy, boxes, token_grad, dfmap);                                           \
+  } while (0)
+    if (dm.c <= 64) PS_TG(1); else if (dm.c <= 128) PS_TG(2); else PS_TG(4);
+#undef PS_TG
+    return PS_OK;
+  }
 #define PS_DF(CPL, NL)                                                                          \
   hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS, NL>), g2, b2, sm2, st, dm, n_work, xy,     \
                      boxes, L, dfmap)

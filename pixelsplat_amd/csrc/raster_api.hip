@@ -366,7 +366,7 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
   if (dfmap) {
     Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
     if (int rc = launch_epipolar_feature_grad(to_dims(d), 1, xy_sample, flags, &qt, &attn, &dfbar,
-                                              &ds, dfmap, ray_boxes, (hipStream_t)stream))
+                                              &ds, dfmap, ray_boxes, nullptr, (hipStream_t)stream))
       return rc;
   }
   return check_launch();
@@ -381,7 +381,30 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* d, int32_t n_layers, const fl
     return PS_ERR_BAD_ARG;
   Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
   if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn,
-                                            dfbar, ds, dfmap, ray_boxes, (hipStream_t)stream))
+                                            dfbar, ds, dfmap, ray_boxes, nullptr,
+                                            (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+size_t ps_epipolar_token_grad_floats(const PsEpipolarDesc* d) {
+  if (!epi_ok(d)) return 0;
+  return (size_t)d->b * d->v * (d->v - 1) * d->h * d->w * d->s * d->c;
+}
+
+int ps_epipolar_feature_grad_two_pass(const PsEpipolarDesc* d, int32_t n_layers,
+                                      const float* xy_sample, const uint8_t* flags,
+                                      const float* const* qt, const float* const* attn,
+                                      const float* const* dfbar, const float* const* ds,
+                                      float* dfmap, uint32_t* ray_boxes, float* token_grad,
+                                      void* stream) {
+  if (!epi_ok(d) || !xy_sample || !flags || !qt || !attn || !dfbar || !ds || !dfmap ||
+      !ray_boxes || !token_grad)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
+  if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn,
+                                            dfbar, ds, dfmap, ray_boxes, token_grad,
+                                            (hipStream_t)stream))
     return rc;
   return check_launch();
 }

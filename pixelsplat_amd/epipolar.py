@@ -204,6 +204,12 @@ def _pad4(n: int) -> int:
     return (n + 3) & ~3
 
 
+# feature-map gradient: two passes (token gradients, then the tile gather) or the single pass
+# that rebuilds every token's gradient per tile; PS_DFMAP_TWO_PASS=0 selects the latter
+import os as _os
+TWO_PASS_FEATURE_GRAD = _os.environ.get("PS_DFMAP_TWO_PASS", "1") != "0"
+
+
 class FeatureGradBatch:
     """Defers the feature-map gradients of attention layers that share one geometry and one
     feature map (the layers of an EpipolarTransformer) so that they are scattered in ONE pass
@@ -248,9 +254,19 @@ class FeatureGradBatch:
             n = len(group)
             arr = lambda k, off=0: (C.c_void_p * n)(*[t[k].data_ptr() + 4 * off for t in group])
             dfmap = torch.empty_like(fmap)
-            _lib.check(lib.ps_epipolar_feature_grad(
-                C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
-                _p(dfmap), _p(boxes), _stream()), "ps_epipolar_feature_grad")
+            if TWO_PASS_FEATURE_GRAD:
+                # token gradients once (d(kv) of the reference, caller-owned scratch), then the
+                # tile gather: a ray's coefficient rows are not reloaded per tile
+                scratch = torch.empty((lib.ps_epipolar_token_grad_floats(C.byref(desc)),),
+                                      dtype=torch.float32, device=fmap.device)
+                _lib.check(lib.ps_epipolar_feature_grad_two_pass(
+                    C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
+                    _p(dfmap), _p(boxes), _p(scratch), _stream()),
+                    "ps_epipolar_feature_grad_two_pass")
+            else:
+                _lib.check(lib.ps_epipolar_feature_grad(
+                    C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
+                    _p(dfmap), _p(boxes), _stream()), "ps_epipolar_feature_grad")
             total = dfmap if total is None else total + dfmap
         return total
 
