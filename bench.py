@@ -51,9 +51,12 @@ def parse():
                    help="N > 1: extra synthetic fp32 gradient payload all-reduced per step, to model "
                         "the rest of the network (the reference reduces ~480 MB; SURVEY.md 5)")
     p.add_argument("--bucket-mb", type=float, default=25.0, help="gradient bucket size (torch DDP default)")
-    p.add_argument("--launch", choices=["graph", "eager"], default="graph",
+    p.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                    help="graph: the step is replayed from two hipGraphs ((A) fwd+bwd, (B) fwd+bwd; "
-                        "fixed-capacity tile lists, no host sync); eager: launch by launch")
+                        "fixed-capacity tile lists, no host sync), the gradient all-reduce launched "
+                        "between them; eager: launch by launch; auto: graph on one GPU, eager on "
+                        "several (capture next to a live RCCL communicator is untested on this "
+                        "pool: the watchdog thread may touch the device during capture)")
     p.add_argument("--cpu-views", type=int, default=16, help="views in the CPU-baseline sample")
     return p.parse_args()
 
@@ -294,9 +297,10 @@ def main():
         torch.cuda.synchronize()
         zero_grads()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        mode = "global" if world == 1 else "thread_local"   # other threads (RCCL watchdog) may
+        with torch.cuda.graph(ga, capture_error_mode=mode):  # call into the runtime meanwhile
             path_a().backward()
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
             path_b().backward()
         graphs["a"], graphs["b"] = ga, gb
 
@@ -395,7 +399,7 @@ def main():
     torch.cuda.empty_cache()
 
     launch_mode = "eager"
-    if args.launch == "graph":
+    if args.launch == "graph" or (args.launch == "auto" and world == 1):
         from pixelsplat_amd.raster import captured_overflow_flags
         list_cap[0] = (int(D_total * 1.25) + 4095) // 4096 * 4096
         try:
