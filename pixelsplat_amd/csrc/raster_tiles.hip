@@ -235,47 +235,111 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   float Ts[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) Ts[k] = live[k] ? 1.f : -1.f;
-  auto blend1 = [&](uint32_t m) {
-    for (uint32_t j = 0; j < m; ++j) {
-      const uint32_t slot = (b_head + j) & (kQB - 1);
-      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
-      const uint32_t hidx = __float_as_uint(q2.y);
-      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+  // one ring entry against the (up to four) quadrants it can reach
+  auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
+    const uint32_t hidx = __float_as_uint(q2.y);
+    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
-          const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
-          const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
-          const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
-          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
-          const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
-          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-          float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
-          asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
-          const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
-          const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
-          const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
-          Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
-          C0[k] = fmaf(q1.z, wgt, C0[k]);
-          C1[k] = fmaf(q1.w, wgt, C1[k]);
-          C2[k] = fmaf(q2.x, wgt, C2[k]);
-          last[k] = (ok & !stop) ? hidx : last[k];
-        }
+    for (int k = 0; k < 4; ++k) {
+      if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
+        const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
+        const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
+        const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
+        const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+        const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
+        const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+        float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
+        asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
+        const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
+        const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
+        const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
+        Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
+        C0[k] = fmaf(q1.z, wgt, C0[k]);
+        C1[k] = fmaf(q1.w, wgt, C1[k]);
+        C2[k] = fmaf(q2.x, wgt, C2[k]);
+        last[k] = (ok & !stop) ? hidx : last[k];
       }
-      if ((j & 7u) == 7u &&
-          !__any((Ts[0] > 0.f) | (Ts[1] > 0.f) | (Ts[2] > 0.f) | (Ts[3] > 0.f))) {
-        all_done = true;
-        break;
+    }
+  };
+  auto every_pixel_stopped = [&]() {
+    return !__any((Ts[0] > 0.f) | (Ts[1] > 0.f) | (Ts[2] > 0.f) | (Ts[3] > 0.f));
+  };
+  auto blend1 = [&](uint32_t m) {
+    if (VAR == 1) {
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t slot = (b_head + j) & (kQB - 1);
+        process_entry(lds.rec[slot][0], lds.rec[slot][1], lds.rec[slot][2]);
+        if ((j & 7u) == 7u && every_pixel_stopped()) { all_done = true; break; }
+      }
+    } else {
+      // VAR 2: two entries per trip, each one's record read from LDS while the other is
+      // blended -- the latency is hidden without moving a prefetched record between registers
+      uint32_t slot = b_head & (kQB - 1);
+      float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
+      for (uint32_t j = 0; j < m; j += 2) {
+        slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
+        const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
+        process_entry(a0, a1, a2);
+        if (j + 1 >= m) break;
+        slot = (b_head + j + 2) & (kQB - 1);
+        a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
+        process_entry(b0, b1, b2);
+        if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
       }
     }
     b_head += m;
     wave_lds_sync();
   };
 
+  if (VAR == 2) {
+    // VAR 2 also takes the refine's two dependent global latencies (list -> record gather) off
+    // the wave's critical path: the records of batch i + 1 and the list indices of batch i + 2
+    // are in flight while batch i is refined and blended
+    auto gather = [&](uint32_t id, float4& r0, float4& r1, float4& r2) {
+      const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
+      r0 = r[0]; r1 = r[1]; r2 = r[2];
+    };
+    auto idx_of = [&](uint32_t first) {
+      return first + (uint32_t)lane < l_count ? list[first + lane] : list[0];
+    };
+    float4 n0, n1, n2;
+    uint32_t id2 = 0;
+    if (l_count > 0) {
+      gather(idx_of(0), n0, n1, n2);
+      id2 = idx_of(kBatch);
+    }
+    for (uint32_t first = 0; first < l_count && !all_done; first += kBatch) {
+      const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
+      const float4 r0 = n0, r1 = n1, r2 = n2;
+      if (first + kBatch < l_count) {
+        gather(id2, n0, n1, n2);
+        id2 = idx_of(first + 2 * kBatch);
+      }
+      bool keep = false;
+      float4 q0, q1, q2;
+      if ((uint32_t)lane < m) {
+        const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
+        const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
+        keep = qm != 0u;
+        q0 = make_float4(r0.x, r0.y, A, B);
+        q1 = make_float4(Cq, r1.y, r2.x, r2.y);
+        q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
+      }
+      const uint64_t mask = __ballot(keep);
+      if (keep) {
+        const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
+        lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
+      }
+      b_tail += (uint32_t)__popcll(mask);
+      wave_lds_sync();
+      while (!all_done && b_tail - b_head >= (uint32_t)kBatch) blend1(kBatch);
+    }
+  } else {
   for (uint32_t first = 0; first < l_count && !all_done; first += kBatch) {
     const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
     refine(first, m);
     while (!all_done && b_tail - b_head >= (uint32_t)kBatch) { if (VAR == 0) blend(kBatch); else blend1(kBatch); }
+  }
   }
   if (!all_done && b_tail != b_head) { if (VAR == 0) blend(b_tail - b_head); else blend1(b_tail - b_head); }
   if (VAR != 0) {
@@ -314,9 +378,12 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  static const int variant = [] { const char* e = getenv("PS_TILES_FWD_VARIANT"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* e = getenv("PS_TILES_FWD_VARIANT"); return e ? atoi(e) : 2; }();
   if (variant == 0)
     hipLaunchKernelGGL(tiles_forward_kernel<0>, grid, block, 0, st, d, records, tile_order, tile_ranges,
+                       point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
+  else if (variant == 2)
+    hipLaunchKernelGGL(tiles_forward_kernel<2>, grid, block, 0, st, d, records, tile_order, tile_ranges,
                        point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
   else
     hipLaunchKernelGGL(tiles_forward_kernel<1>, grid, block, 0, st, d, records, tile_order, tile_ranges,
@@ -371,8 +438,9 @@ __device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float 
 
 // VAR 0: round-1 loop (LDS prefetch rotated through a second register set); VAR 1: the record of
 // entry j is read where it is used, (dx, dy) / (B dy, C dy) as 2-vectors.
-template <int VAR>
-__global__ void __launch_bounds__(kWavesPerBlock* kWave, 4)
+// WPS: waves per SIMD the register allocation is held to (4 -> 128 VGPRs, a few spills; 3 -> 168)
+template <int VAR, int WPS>
+__global__ void __launch_bounds__(kWavesPerBlock* kWave, WPS)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_ranges,
@@ -448,11 +516,20 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   uint32_t b_head = 0, b_tail = 0;
 
   // refine list entries with 1-based indices top, top-1, ..., top-m+1 (lane i takes top - i)
+  // list index of this lane's entry in the batch whose first (highest) 1-based index is `top`;
+  // VAR 1 loads it one batch ahead, which takes the first of the refine's two dependent global
+  // latencies (list -> record gather) off the critical path for one register
+  auto idx_of = [&](uint32_t top) {
+    return (uint32_t)lane < top ? list[top - 1u - lane] : list[0];
+  };
+  uint32_t id_ahead = c_max > 0 ? idx_of(c_max) : 0u;
   auto refine = [&](uint32_t top, uint32_t m) {
     bool keep = false;
     float4 q0, q1, q2;
+    const uint32_t id_now = VAR == 0 ? 0u : id_ahead;
+    if (VAR != 0 && top > m) id_ahead = idx_of(top - m);
     if ((uint32_t)lane < m) {
-      const uint32_t id = list[top - 1u - lane];
+      const uint32_t id = VAR == 0 ? list[top - 1u - lane] : id_now;
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
       const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
@@ -602,14 +679,14 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
   static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 1; }();
-  if (variant == 0)
-    hipLaunchKernelGGL(tiles_backward_kernel<0>, grid, block, 0, st, d, records, tile_order,
-                       tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end,
-                       dL_dcolor, grad2d, tile_grads);
-  else
-    hipLaunchKernelGGL(tiles_backward_kernel<1>, grid, block, 0, st, d, records, tile_order,
-                       tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end,
-                       dL_dcolor, grad2d, tile_grads);
+#define PS_BWD(V, W)                                                                             \
+  hipLaunchKernelGGL((tiles_backward_kernel<V, W>), grid, block, 0, st, d, records, tile_order,   \
+                     tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end, \
+                     dL_dcolor, grad2d, tile_grads)
+  if (variant == 0) PS_BWD(0, 4);
+  else if (variant == 3) PS_BWD(1, 3);
+  else PS_BWD(1, 4);
+#undef PS_BWD
 }
 
 }  // namespace ps
