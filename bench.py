@@ -61,50 +61,52 @@ def parse():
     return p.parse_args()
 
 
-# profile groups that are ONE kernel (their event time is that kernel's duration)
+# profile groups whose event time is the duration of these kernels (substrings of their names)
 SINGLE_KERNEL_GROUPS = {
-    "tiles_backward": "tiles_backward_kernel", "tiles_forward": "tiles_forward_kernel",
-    "epipolar_attention_forward": "epipolar_attn_forward_kernel",
-    "epipolar_attention_backward": "epipolar_attn_backward_kernel",
-    "epipolar_feature_grad": "epipolar_dfmap_kernel",
-    "gaussian_adapter_backward": "adapter_backward_kernel<4, 0>",
-    "depth_sampler_forward": "depth_sampler_forward_kernel",
-    "depth_sampler_backward": "depth_sampler_backward_kernel",
+    "tiles_backward": ["tiles_backward_kernel"], "tiles_forward": ["tiles_forward_kernel"],
+    "epipolar_attention_forward": ["epipolar_attn_forward_kernel"],
+    "epipolar_attention_backward": ["epipolar_attn_backward_kernel"],
+    "epipolar_feature_grad": ["epipolar_token_grad_kernel", "epipolar_dfmap_gather_kernel",
+                              "epipolar_dfmap_kernel"],
+    "gaussian_adapter_backward": ["adapter_backward_kernel<4, 0>"],
+    "depth_sampler_forward": ["depth_sampler_forward_kernel"],
+    "depth_sampler_backward": ["depth_sampler_backward_kernel"],
 }
+PMC_TAG = None    # "c2" | "c4" | "c5": which committed counter summaries match this run
+
+
+def _pmc_file(kind):
+    import glob
+    if PMC_TAG is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{PMC_TAG}_pmc_{kind}.json")))
+    return files[-1] if files else None
 
 
 def pmc_traffic(group):
-    """HBM-side bytes per launch of the kernel behind a profile group, from the committed
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (tools/pmc_summary.py; counters cannot be
-    read from inside the process).  None when no summary is committed or the group is not a
-    single kernel."""
-    import glob
-    key = SINGLE_KERNEL_GROUPS.get(group)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if key is None or not files:
+    """HBM-side bytes per launch of the kernel(s) behind a profile group, from the committed
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of the SAME workload (tools/pmc_summary.py;
+    counters cannot be read from inside the process).  None when there is no summary."""
+    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("traffic")
+    if keys is None or path is None:
         return None, None
-    with open(files[-1]) as f:
+    with open(path) as f:
         kernels = json.load(f)["kernels"]
-    for name, v in kernels.items():
-        if key in name:
-            return float(v["bytes"]), os.path.basename(files[-1])
-    return None, None
+    total = sum(float(v["bytes"]) for name, v in kernels.items() if any(k in name for k in keys))
+    return (total, os.path.basename(path)) if total else (None, None)
 
 
 def pmc_valu_busy_ms(group):
-    """VALU-issue time per launch (SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs at 2.4 GHz) of
-    the kernel behind a profile group, from the committed PMC summary (tools/pmc_sq_summary.py)."""
-    import glob
-    key = SINGLE_KERNEL_GROUPS.get(group)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq.json")))
-    if key is None or not files:
+    """VALU-busy time per launch (SQ_ACTIVE_INST_VALU quad-cycles x 4 / 1024 SIMDs at 2.4 GHz) of
+    the kernel(s) behind a profile group, from the committed PMC summary (tools/pmc_sq_summary.py)."""
+    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("sq")
+    if keys is None or path is None:
         return None
-    with open(files[-1]) as f:
+    with open(path) as f:
         kernels = json.load(f)["kernels"]
-    for name, v in kernels.items():
-        if key in name:
-            return v.get("valu_busy_ms_at_2.4GHz")
-    return None
+    tot = sum(v.get("valu_busy_ms_at_2.4GHz", 0.0) for name, v in kernels.items()
+              if any(k in name for k in keys))
+    return tot or None
 
 
 def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
@@ -498,9 +500,12 @@ def main():
         dom = max(alg, key=lambda k: groups[k][0])
         dom_ms = groups[dom][0]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
-        # the committed PMC summaries were taken on the configs[1] workload
-        is_c2 = (hw[0], hw[1], b, v, vc) == (256, 256, 7, 4, 2)
-        traffic, traffic_src = pmc_traffic(dom) if is_c2 else (None, None)
+        # committed PMC summaries exist for the three benchmarked BASELINE configurations
+        global PMC_TAG
+        PMC_TAG = {(256, 256, 7, 4, 2): "c2", (256, 256, 4, 4, 3): "c4",
+                   (512, 512, 2, 4, 2): "c5"}.get((hw[0], hw[1], b, v, vc))
+        is_c2 = PMC_TAG is not None
+        traffic, traffic_src = pmc_traffic(dom)
         valu_ms = pmc_valu_busy_ms(dom) if is_c2 else None
         out = {
             "metric": "rendered views/sec (fwd+bwd)", "value": round(value, 2), "unit": "views/s",
