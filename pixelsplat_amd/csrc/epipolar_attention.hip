@@ -290,27 +290,42 @@ __device__ __forceinline__ void stage_chunk(const AttnDims& dm, const RayCtx& k,
     k.peS[tl * k.Ps + p] = pe_value(k.rdS[t], p);
   }
   const int lt = lane / LPT, ch = (lane % LPT) * 4;
+  // TPS tokens per pass; the corner loads of NB passes are issued together (8 x 16 bytes per
+  // lane in flight at c = 128): a pass-at-a-time loop waits one full load latency per pass,
+  // 16 serialized latencies per ray
+  constexpr int PASSES = (kChunk + TPS - 1) / TPS;
+  constexpr int NB = PASSES >= 2 ? 2 : 1;
+  const char* fm = reinterpret_cast<const char*>(fmap);
+  // 32-bit byte offsets from the (wave-uniform) map pointer: scalar base + vector offset
+  // addressing instead of a 64-bit multiply-add per corner (the maps are < 4 GB, checked)
+  const uint32_t cb = 4u * (uint32_t)dm.c, chb = 4u * (uint32_t)ch;
 #pragma unroll
-  for (int s0 = 0; s0 < kChunk; s0 += TPS) {
-    const int tl = s0 + lt;
-    const int t = t0 + tl;
-    if (tl < kChunk && t < k.T && ch < dm.c) {
-      const int4 off = *reinterpret_cast<const int4*>(k.tokS + t * 8);
-      const float4 wt = *reinterpret_cast<const float4*>(k.tokS + t * 8 + 4);
-      // 32-bit byte offsets from the (wave-uniform) map pointer: scalar base + vector offset
-      // addressing instead of a 64-bit multiply-add per corner (the maps are < 4 GB, checked)
-      const char* fm = reinterpret_cast<const char*>(fmap);
-      const uint32_t cb = 4u * (uint32_t)dm.c, chb = 4u * (uint32_t)ch;
-      const float4 p0 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.x * cb + chb));
-      const float4 p1 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.y * cb + chb));
-      const float4 p2 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.z * cb + chb));
-      const float4 p3 = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.w * cb + chb));
+  for (int s0 = 0; s0 < kChunk; s0 += NB * TPS) {
+    float4 p[NB][4], wt[NB];
+    bool on[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int tl = s0 + u * TPS + lt;
+      const int t = t0 + tl;
+      on[u] = tl < kChunk && t < k.T && ch < dm.c;
+      const int tc = on[u] ? t : 0;                     // clamped: the loads are unconditional
+      const int4 off = *reinterpret_cast<const int4*>(k.tokS + tc * 8);
+      wt[u] = *reinterpret_cast<const float4*>(k.tokS + tc * 8 + 4);
+      const uint32_t chq = on[u] ? chb : 0u;
+      p[u][0] = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.x * cb + chq));
+      p[u][1] = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.y * cb + chq));
+      p[u][2] = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.z * cb + chq));
+      p[u][3] = *reinterpret_cast<const float4*>(fm + ((uint32_t)off.w * cb + chq));
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int tl = s0 + u * TPS + lt;
       float4 f;
-      f.x = fmaf(p3.x, wt.w, fmaf(p2.x, wt.z, fmaf(p1.x, wt.y, p0.x * wt.x)));
-      f.y = fmaf(p3.y, wt.w, fmaf(p2.y, wt.z, fmaf(p1.y, wt.y, p0.y * wt.x)));
-      f.z = fmaf(p3.z, wt.w, fmaf(p2.z, wt.z, fmaf(p1.z, wt.y, p0.z * wt.x)));
-      f.w = fmaf(p3.w, wt.w, fmaf(p2.w, wt.z, fmaf(p1.w, wt.y, p0.w * wt.x)));
-      *reinterpret_cast<float4*>(k.featS + tl * k.fs + ch) = f;
+      f.x = fmaf(p[u][3].x, wt[u].w, fmaf(p[u][2].x, wt[u].z, fmaf(p[u][1].x, wt[u].y, p[u][0].x * wt[u].x)));
+      f.y = fmaf(p[u][3].y, wt[u].w, fmaf(p[u][2].y, wt[u].z, fmaf(p[u][1].y, wt[u].y, p[u][0].y * wt[u].x)));
+      f.z = fmaf(p[u][3].z, wt[u].w, fmaf(p[u][2].z, wt[u].z, fmaf(p[u][1].z, wt[u].y, p[u][0].z * wt[u].x)));
+      f.w = fmaf(p[u][3].w, wt[u].w, fmaf(p[u][2].w, wt[u].z, fmaf(p[u][1].w, wt[u].y, p[u][0].w * wt[u].x)));
+      if (on[u]) *reinterpret_cast<float4*>(k.featS + tl * k.fs + ch) = f;
     }
   }
   wave_lds_sync();
@@ -353,19 +368,30 @@ __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k
                                              int hs_e, float (&out)[kMaxHeads]) {
   const int tl = lane >> 3, j = lane & 7;
   const float* frow = k.featS + tl * k.fs;
-  float acc[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
+  // even / odd components accumulate in the two halves of a register pair: the packed FMAs
+  // then take the (x, y) and (z, w) halves of the 16-byte LDS reads in place (the scalar form
+  // is packed by the compiler across HEADS, which costs a v_mov per operand to build the pairs)
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v2 acc2[kMaxHeads];
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) acc2[hh] = v2{0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < CK / 32; ++i) {
     const int ch = 4 * (j + 8 * i);
     if (ch < dm.c) {
       const float4 f = *reinterpret_cast<const float4*>(frow + ch);
+      const v2 f01 = v2{f.x, f.y}, f23 = v2{f.z, f.w};
 #pragma unroll
       for (int hh = 0; hh < kMaxHeads; ++hh) {
         const float4 q = *reinterpret_cast<const float4*>(k.qS + hh * dm.c + ch);
-        acc[hh] = fmaf(q.w, f.w, fmaf(q.z, f.z, fmaf(q.y, f.y, fmaf(q.x, f.x, acc[hh]))));
+        acc2[hh] = v2{q.x, q.y} * f01 + acc2[hh];
+        acc2[hh] = v2{q.z, q.w} * f23 + acc2[hh];
       }
     }
   }
+  float acc[kMaxHeads];
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] = acc2[hh].x + acc2[hh].y;
   const float* prow = k.peS + tl * k.Ps;
 #pragma unroll
   for (int i = 0; i < kUPL; ++i) {
@@ -410,9 +436,9 @@ struct ContextRegs {
 
 // phase F: acc += sum over the chunk's tokens of wgt_{h,t} (feat_t | pe_t | [ov(t) == lane]);
 // wgt lives in lane 8*tl + 7
-template <int CK>
+template <int CK, bool WITH_O>
 __device__ __forceinline__ void chunk_context(const AttnDims& dm, const RayCtx& k, int lane, int t0,
-                                              const float (&wgt)[kMaxHeads], bool with_o,
+                                              const float (&wgt)[kMaxHeads],
                                               ContextRegs<CK>& A) {
   constexpr int CPL = ContextRegs<CK>::CPL;
   const int c0 = lane * CPL;
@@ -431,13 +457,15 @@ __device__ __forceinline__ void chunk_context(const AttnDims& dm, const RayCtx& 
 #pragma unroll
       for (int i = 0; i < CPL; ++i) A.f[hh][i] = fmaf(a, f[i], A.f[hh][i]);
       A.p[hh] = fmaf(a, pe, A.p[hh]);
-      if (with_o) A.o[hh] += mine ? a : 0.f;
+      // compile-time: as a run-time flag this became 20 selects / moves per token, executed
+      // (and thrown away) in every 2-view run, where there is no view embedding
+      if (WITH_O) A.o[hh] += mine ? a : 0.f;
     }
     ov = ov + 1 == k.ovn ? 0 : ov + 1;
   }
 }
 
-template <int CK>
+template <int CK, bool WITH_O>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
                              const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -492,7 +520,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     for (int hh = 0; hh < kMaxHeads; ++hh)
       l_run[hh] = uniform(fmaf(l_run[hh], corr[hh], lane_bcast(ps[hh], 63)));
     A.scale(corr);
-    chunk_context<CK>(dm, k, lane, t0, sc, e != nullptr, A);
+    chunk_context<CK, WITH_O>(dm, k, lane, t0, sc, A);
     wave_lds_sync();        // the chunk buffers are overwritten by the next iteration
   }
 
@@ -520,7 +548,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
 // so the weighted sums use w_t = a_t da_t, known per chunk, and the forward outputs
 // (fbar, pbar, abar) close the expression -- no second gather.
 // ------------------------------------------------------------------------------------
-template <int CK>
+template <int CK, bool WITH_O>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
                               const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -546,6 +574,16 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   A.clear();
   float dot[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
   const bool score_lane = (lane & 7) == 7;
+  // the ray's attention weights, lanes <-> tokens (T <= 128: two per lane), loaded ONCE up front:
+  // a load inside the chunk loop put one more dependent global latency into every chunk
+  float aw[2][kMaxHeads];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh) {
+      const int t = lane + u * kWave;
+      aw[u][hh] = (t < k.T && hh < k.H) ? attn[(rh + hh) * k.T + t] : 0.f;
+    }
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float da[kMaxHeads];
@@ -555,13 +593,17 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
 #pragma unroll
     for (int hh = 0; hh < kMaxHeads; ++hh) {
       const bool on = live && hh < k.H;
-      const float a = on ? attn[(rh + hh) * k.T + t] : 0.f;
+      // token t sits in lane t % 64, register t / 64 (t0 is wave-uniform, a chunk never
+      // straddles the two registers)
+      const float a_src = t0 < kWave ? aw[0][hh] : aw[1][hh];
+      const float a_t = __shfl(a_src, t & (kWave - 1));
+      const float a = on ? a_t : 0.f;
       if (on) k.scS[hh * k.T + t] = da[hh];
       da[hh] = a * da[hh];
       if (!on) da[hh] = 0.f;
       dot[hh] += da[hh];
     }
-    chunk_context<CK>(dm, k, lane, t0, da, true, A);
+    chunk_context<CK, WITH_O>(dm, k, lane, t0, da, A);
     wave_lds_sync();
   }
   wave_sum4_to_lane63(dot[0], dot[1], dot[2], dot[3]);
@@ -585,9 +627,11 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
       const float ab = abar ? abar[ray * dm.ld_a + hh * dm.hs_a + lane] : 1.0f;
       de[ray * dm.ld_e + hh * dm.hs_e + lane] = scale * (A.o[hh] - d * ab);
     }
-    for (int t = lane; t < k.T; t += kWave)
-      ds_out[(rh + hh) * k.T + t] =
-          scale * attn[(rh + hh) * k.T + t] * (k.scS[hh * k.T + t] - d);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = lane + u * kWave;
+      if (t < k.T) ds_out[(rh + hh) * k.T + t] = scale * aw[u][hh] * (k.scS[hh * k.T + t] - d);
+    }
   }
 }
 
@@ -1144,15 +1188,18 @@ int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const fl
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
   const size_t sm = attn_smem(dm);
-#define PS_GO(L)                                                                                \
+#define PS_GO2(L, O)                                                                            \
   do {                                                                                          \
-    static const bool lds_ok_ = (hipFuncSetAttribute((const void*)epipolar_attn_forward_kernel<L>,                \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;             \
-    hipLaunchKernelGGL(epipolar_attn_forward_kernel<L>, grid, block, sm, st, dm, fmap, xy,      \
+    static const bool lds_ok_ = (hipFuncSetAttribute(                                           \
+        (const void*)epipolar_attn_forward_kernel<L, O>,                                        \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;          \
+    hipLaunchKernelGGL((epipolar_attn_forward_kernel<L, O>), grid, block, sm, st, dm, fmap, xy, \
                        flags, rd, qt, u, e, scale, fbar, pbar, abar, attn);                     \
   } while (0)
+#define PS_GO(L) do { if (e != nullptr) PS_GO2(L, true); else PS_GO2(L, false); } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO
+#undef PS_GO2
   return PS_OK;
 }
 
@@ -1166,16 +1213,19 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
   const size_t sm = attn_smem(dm);
-#define PS_GO(L)                                                                                \
+#define PS_GO2(L, O)                                                                            \
   do {                                                                                          \
-    static const bool lds_ok_ = (hipFuncSetAttribute((const void*)epipolar_attn_backward_kernel<L>,                \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;             \
-    hipLaunchKernelGGL(epipolar_attn_backward_kernel<L>, grid, block, sm, st, dm, fmap, xy,     \
-                       flags, rd, attn, fbar, pbar, abar, dfbar, dpbar, dabar, scale, dqt, du,  \
-                       de, ds);                                                                 \
+    static const bool lds_ok_ = (hipFuncSetAttribute(                                           \
+        (const void*)epipolar_attn_backward_kernel<L, O>,                                       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;          \
+    hipLaunchKernelGGL((epipolar_attn_backward_kernel<L, O>), grid, block, sm, st, dm, fmap,    \
+                       xy, flags, rd, attn, fbar, pbar, abar, dfbar, dpbar, dabar, scale, dqt,  \
+                       du, de, ds);                                                             \
   } while (0)
+#define PS_GO(L) do { if (de != nullptr) PS_GO2(L, true); else PS_GO2(L, false); } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO
+#undef PS_GO2
   return PS_OK;
 }
 

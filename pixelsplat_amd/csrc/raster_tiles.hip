@@ -514,6 +514,12 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
   const uint64_t lt = lanemask_lt();
   uint32_t b_head = 0, b_tail = 0;
+  // VAR 2 keeps the per-pixel colour state as 2-vectors (channels 0,1 | channel 2) so that the
+  // packed instructions take their operands in place (the auto-vectoriser packs the scalar form
+  // too, but assembles the register pairs with ~5 v_mov per pixel and entry)
+  f32x2 acc01[4], g01[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { acc01[k] = f32x2{0.f, 0.f}; g01[k] = f32x2{g0[k], g1[k]}; }
 
   // refine list entries with 1-based indices top, top-1, ..., top-m+1 (lane i takes top - i)
   // list index of this lane's entry in the batch whose first (highest) 1-based index is `top`;
@@ -562,25 +568,53 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     wave_lds_sync();
   };
 
-  auto blend = [&](uint32_t m) {
-    float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
-           n2 = lds.rec[b_head & (kQB - 1)][2];
-    for (uint32_t j = 0; j < m; ++j) {
-      float4 q0, q1, q2;
-      if (VAR == 0) {
-        q0 = n0; q1 = n1; q2 = n2;
-        const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
-        n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
-      } else {
-        const uint32_t slot = (b_head + j) & (kQB - 1);
-        q0 = lds.rec[slot][0]; q1 = lds.rec[slot][1]; q2 = lds.rec[slot][2];
-      }
+  // one ring entry: the pixels' updates, the nine wave sums, their hand-over through LDS
+  auto entry = [&](uint32_t j, const float4 q0, const float4 q1, const float4 q2) {
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
       const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
       float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
       float s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
       bool any = false;
+      if (VAR == 2 || VAR == 4) {
+        f32x2 M1 = {0.f, 0.f}, M2 = {0.f, 0.f}, s_rg = {0.f, 0.f};   // (Mx, My) (Mxx, Mxy) (s_r, s_g)
+        const f32x2 c01 = f32x2{c0, c1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (qm & (1u << k)) {   // wave-uniform quadrant skip
+            const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};
+            const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};        // (B dy, C dy)
+            const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);
+            const float Gv = fast_exp2(pw);
+            float alpha;                                   // min(alpha_max, o G) in one instruction
+            asm("v_min_f32 %0, %1, %2" : "=v"(alpha) : "s"(alpha_max), "v"(o * Gv));
+            const bool ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
+            const float ale = ok ? alpha : 0.f;            // 0 => all updates are no-ops
+            const float rcp = __builtin_amdgcn_rcpf(1.f - ale);   // 1 ulp; exact 1 when ale == 0
+            const float Tn = T[k] * rcp;                    // T in front of this entry
+            const f32x2 d01 = c01 - acc01[k];
+            const float d2 = c2 - acc2[k];
+            const f32x2 t01 = d01 * g01[k];
+            float dL_dalpha = fmaf(d2, g2[k], t01.x + t01.y) * Tn;
+            dL_dalpha = fmaf(Tfb[k], rcp, dL_dalpha);       // -T_final/(1-alpha) * bg.dL/dC
+            const float dch = ale * Tn;
+            s_rg = f32x2{dch, dch} * g01[k] + s_rg;
+            s_b = fmaf(dch, g2[k], s_b);
+            const float gda = ok ? Gv * dL_dalpha : 0.f;    // G * dL/dalpha
+            s_op += gda;
+            const float q = o * gda;                        // G * dL/dG
+            const f32x2 qxy = f32x2{q, q} * dd;             // (q dx, q dy)
+            M1 += qxy;
+            M2 = f32x2{qxy.x, qxy.x} * dd + M2;             // (Mxx, Mxy) += q dx (dx, dy)
+            Myy = fmaf(qxy.y, dd.y, Myy);
+            T[k] = Tn;
+            acc01[k] = f32x2{ale, ale} * d01 + acc01[k];    // alpha c + (1 - alpha) acc
+            acc2[k] = fmaf(ale, d2, acc2[k]);
+            any |= ok;
+          }
+        }
+        Mx = M1.x; My = M1.y; Mxx = M2.x; Mxy = M2.y; s_r = s_rg.x; s_g = s_rg.y;
+      } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (qm & (1u << k)) {   // wave-uniform quadrant skip
@@ -613,6 +647,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
           any |= ok;
         }
       }
+      }
       if (__any(any)) {
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         float r1, r2;
@@ -626,6 +661,36 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         }
       } else if (lane == 63) {
         lds.gsum[j][9] = 0.f;
+      }
+  };
+
+  auto blend = [&](uint32_t m) {
+    if (VAR == 0) {
+      float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
+             n2 = lds.rec[b_head & (kQB - 1)][2];
+      for (uint32_t j = 0; j < m; ++j) {
+        const float4 q0 = n0, q1 = n1, q2 = n2;
+        const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
+        n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
+        entry(j, q0, q1, q2);
+      }
+    } else if (VAR == 4) {
+      // two entries per trip, each one's record read from LDS while the other is processed
+      uint32_t slot = b_head & (kQB - 1);
+      float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
+      for (uint32_t j = 0; j < m; j += 2) {
+        slot = (b_head + j + 1) & (kQB - 1);                   // (stale beyond m: never processed)
+        const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
+        entry(j, a0, a1, a2);
+        if (j + 1 >= m) break;
+        slot = (b_head + j + 2) & (kQB - 1);
+        a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
+        entry(j + 1, b0, b1, b2);
+      }
+    } else {
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t slot = (b_head + j) & (kQB - 1);
+        entry(j, lds.rec[slot][0], lds.rec[slot][1], lds.rec[slot][2]);
       }
     }
     wave_lds_sync();
@@ -678,14 +743,16 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 2; }();
 #define PS_BWD(V, W)                                                                             \
   hipLaunchKernelGGL((tiles_backward_kernel<V, W>), grid, block, 0, st, d, records, tile_order,   \
                      tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end, \
                      dL_dcolor, grad2d, tile_grads)
   if (variant == 0) PS_BWD(0, 4);
   else if (variant == 3) PS_BWD(1, 3);
-  else PS_BWD(1, 4);
+  else if (variant == 1) PS_BWD(1, 4);
+  else if (variant == 4) PS_BWD(4, 4);
+  else PS_BWD(2, 4);
 #undef PS_BWD
 }
 

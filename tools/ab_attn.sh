@@ -1,0 +1,5 @@
+python -m pytest tests/test_epipolar_gpu.py -m gpu -x -q 2>&1 | tail -2
+for cfg in "" "--context-views 3 --batch 4"; do
+python bench.py $cfg --steps 20 --warmup 3 --no-cpu-baseline --launch eager 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; print('[$cfg]', 'step', d['ms_per_step'], 'A', d['paths']['epipolar_only_ms_per_step'], 'attn_fwd', k['epipolar_attention_forward'], 'attn_bwd', k['epipolar_attention_backward'], 'fgrad', k['epipolar_feature_grad'], 'tiles', k['tiles_forward'], k['tiles_backward'])"
+done
