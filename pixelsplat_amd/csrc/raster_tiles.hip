@@ -436,9 +436,16 @@ __device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float 
       : "+v"(r1), "+v"(r2), "+v"(i));
 }
 
-// VAR 0: round-1 loop (LDS prefetch rotated through a second register set); VAR 1: the record of
-// entry j is read where it is used, (dx, dy) / (B dy, C dy) as 2-vectors.
-// WPS: waves per SIMD the register allocation is held to (4 -> 128 VGPRs, a few spills; 3 -> 168)
+// Variants (PS_TILES_BWD_VARIANT selects; measured at BASELINE configs[1]):
+//   0  round-1 loop: LDS prefetch rotated through a second register set        2.14 ms
+//   1  record read where it is used, (dx, dy) / (B dy, C dy) as 2-vectors       2.06 ms (11 spills)
+//   2  + the per-pixel colour state and the sums kept as 2-vectors, so the packed
+//      instructions take their operands in place (no v_mov to build pairs; 116
+//      VGPRs, no spill), min(alpha_max, .) in one instruction                   1.90 ms
+//   4  (default) 2 + two entries per trip, each record read from LDS while the
+//      other entry is processed                                                 1.88 ms
+//   3  = 1 held to 3 waves/SIMD (168 VGPRs, no spill)                            2.17 ms
+// WPS: waves per SIMD the register allocation is held to (4 -> 128 VGPRs; 3 -> 168)
 template <int VAR, int WPS>
 __global__ void __launch_bounds__(kWavesPerBlock* kWave, WPS)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
@@ -743,7 +750,7 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 2; }();
+  static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 4; }();
 #define PS_BWD(V, W)                                                                             \
   hipLaunchKernelGGL((tiles_backward_kernel<V, W>), grid, block, 0, st, d, records, tile_order,   \
                      tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end, \

@@ -139,3 +139,39 @@ def test_launch_ranks_runs_the_script_as_n_ranks(capfd):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["t"] == 2.0 and rec["out"] == ["--steps", "3"]
     assert rec["grad"] == [0.0, 1.5, 3.0, 4.5, 6.0]     # mean of (1x, 2x) arange
+
+
+def _reduce_now_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from pixelsplat_amd import parallel as P
+
+    P.init_from_env("gloo")
+    ws = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 300, 7)]
+    red = P.GradientReducer(ws, world, bucket_bytes=1024)
+    # static gradient tensors, as a replayed hipGraph leaves them (no accumulate hook fires)
+    ws[0].grad = torch.arange(5.0) * (rank + 1)
+    ws[1].grad = torch.full((300,), float(rank))
+    keep = [w.grad for w in ws[:2]]
+    red.reduce_now()
+    red.finish()
+    out[rank] = ([w.grad.clone() for w in ws], [w.grad is k for w, k in zip(ws, keep)], dict(red.stats))
+    P.shutdown(world)
+
+
+def test_gradient_reducer_hook_free_variant_for_graph_replays():
+    """reduce_now(): gradients copied into the buckets, reduced, means copied BACK into the same
+    gradient tensors (a replayed graph keeps writing into them); a parameter without a gradient
+    counts as zero and receives the mean."""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_reduce_now_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        grads, same_storage, stats = res[rank]
+        torch.testing.assert_close(grads[0], torch.arange(5.0) * 1.5)
+        torch.testing.assert_close(grads[1], torch.full((300,), 0.5))
+        torch.testing.assert_close(grads[2], torch.zeros(7))
+        assert same_storage == [True, True]
+        assert stats["launches"] == stats["buckets"] >= 2
