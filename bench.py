@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--context-views", type=int, default=2,
                    help="context views per scene (3: BASELINE configs[3], acid 3-view)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-probes", action="store_true",
+                   help="skip the SURVEY 8(f) side probes (adapter / depth / head chain) after the timed "
+                        "region: for profiling the step alone")
     p.add_argument("--grad-payload-mb", type=float, default=0.0,
                    help="N > 1: extra synthetic fp32 gradient payload all-reduced per step, to model "
                         "the rest of the network (the reference reduces ~480 MB; SURVEY.md 5)")
@@ -452,18 +455,21 @@ def main():
     # outside the contract's timed region: each path alone
     ms_b = timed(lambda: step(a=False), args.steps)
     ms_a = timed(lambda: step(b_=False), args.steps)
-    step_adapter()
-    step_depth()
-    lib.ps_profile_enable(1)
-    ms_ga = timed(step_adapter, args.steps)
-    ms_dp = timed(step_depth, args.steps)
-    lib.ps_profile_enable(0)
-    try:
-        step_chain()
-        ms_chain = timed(step_chain, args.steps)
-    except RuntimeError as err:   # e.g. PS_ERR_CAPACITY for a degenerate random scene
-        print(f"[bench] chain probe skipped: {err}", file=sys.stderr)
-        ms_chain = None
+    ms_ga = ms_dp = 0.0
+    ms_chain = None
+    if not args.no_probes:
+        step_adapter()
+        step_depth()
+        lib.ps_profile_enable(1)
+        ms_ga = timed(step_adapter, args.steps)
+        ms_dp = timed(step_depth, args.steps)
+        lib.ps_profile_enable(0)
+        try:
+            step_chain()
+            ms_chain = timed(step_chain, args.steps)
+        except RuntimeError as err:   # e.g. PS_ERR_CAPACITY for a degenerate random scene
+            print(f"[bench] chain probe skipped: {err}", file=sys.stderr)
+            ms_chain = None
     side_ms = (C.c_double * ng)()
     side_n = (C.c_int64 * ng)()
     _lib.check(lib.ps_profile_collect(side_ms, side_n), "ps_profile_collect")
