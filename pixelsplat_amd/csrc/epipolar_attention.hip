@@ -656,25 +656,95 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
 // The summation order is fixed (view, ray, sample, corner): the gradient is bit-reproducible,
 // which atomics never were.  Every pixel is written exactly once; dfmap needs no memset.
 // ------------------------------------------------------------------------------------
+// `tile_work` (optional): per (source image, TS x TS tile) a work estimate for the two-pass
+// gather, which orders its blocks by it (longest first): the number of ray boxes that overlap
+// the tile, long thin boxes of slanted lines weighted down.  Neighbouring rays have nearly the
+// same box, so the counts are pre-aggregated in an LDS histogram per block of 256 rays (global
+// atomics straight from the rays cost 0.33 ms at configs[3]) and only its non-zero bins go out.
+template <int TS>
 __global__ void __launch_bounds__(256)
 epipolar_ray_box_kernel(AttnDims dm, const float* __restrict__ xy,
-                        const uint8_t* __restrict__ flags, uint32_t* __restrict__ boxes) {
-  const size_t n = (size_t)dm.b * dm.v * (dm.v - 1) * dm.h * dm.w;
-  const size_t ro = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ro >= n) return;
-  uint32_t box = 0x00FF00FFu;                       // empty: min 255 > max 0
-  if (flags[ro] & 1) {
-    const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s));
-    const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s + dm.s - 1));
-    const Corner a = corner_of(p0.x, p0.y, dm.w, dm.h), c = corner_of(p1.x, p1.y, dm.w, dm.h);
-    // the samples lie on the segment between the first and the last one; one pixel of slack
-    // for the rounding of the interpolation, then the +1 corner
-    const int x0 = max(min(a.x0, c.x0) - 1, 0), x1 = min(max(a.x0, c.x0) + 2, dm.w - 1);
-    const int y0 = max(min(a.y0, c.y0) - 1, 0), y1 = min(max(a.y0, c.y0) + 2, dm.h - 1);
-    if (x0 <= x1 && y0 <= y1)
-      box = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24);
+                        const uint8_t* __restrict__ flags, uint32_t* __restrict__ boxes,
+                        uint32_t* __restrict__ tile_work) {
+  extern __shared__ uint32_t hist[];                // [tiles] when tile_work != nullptr
+  const int R = dm.h * dm.w, ovn = dm.v - 1;
+  const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
+  const int tiles = tiles_x * tiles_y;
+  const size_t n = (size_t)dm.b * dm.v * ovn * R;
+  const size_t ro_first = (size_t)blockIdx.x * blockDim.x;
+  const size_t ro = ro_first + threadIdx.x;
+  // all rays of the block look into the same source image?  (always when 256 divides h*w)
+  const size_t ro_last = min(ro_first + blockDim.x, n) - 1;
+  const bool one_src = tile_work != nullptr && ro_first / R == ro_last / R;
+  if (one_src) {
+    for (int i = threadIdx.x; i < tiles; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
   }
-  boxes[ro] = box;
+  size_t src = 0;
+  if (ro < n) {
+    uint32_t box = 0x00FF00FFu;                       // empty: min 255 > max 0
+    if (flags[ro] & 1) {
+      const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s));
+      const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (ro * dm.s + dm.s - 1));
+      const Corner a = corner_of(p0.x, p0.y, dm.w, dm.h), c = corner_of(p1.x, p1.y, dm.w, dm.h);
+      // the samples lie on the segment between the first and the last one; one pixel of slack
+      // for the rounding of the interpolation, then the +1 corner
+      const int x0 = max(min(a.x0, c.x0) - 1, 0), x1 = min(max(a.x0, c.x0) + 2, dm.w - 1);
+      const int y0 = max(min(a.y0, c.y0) - 1, 0), y1 = min(max(a.y0, c.y0) + 2, dm.h - 1);
+      if (x0 <= x1 && y0 <= y1) {
+        box = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24);
+        if (tile_work != nullptr) {
+          // source image of this ray: (b, other view ov of casting view v)
+          const int ov = (int)((ro / R) % ovn);
+          const size_t bv = ro / ((size_t)R * ovn);
+          const int v = (int)(bv % dm.v);
+          src = bv - v + (ov < v ? ov : ov + 1);
+          const int tx0 = x0 / TS, tx1 = x1 / TS, ty0 = y0 / TS, ty1 = y1 / TS;
+          const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+          // ~16 x (tiles the segment crosses / tiles in its box); only the ORDER of the blocks
+          // depends on the estimate
+          const uint32_t wgt = (uint32_t)max(1, 16 / min(nx, ny));
+          uint32_t* tw = one_src ? hist : tile_work + src * (size_t)tiles;
+          for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(tw + ty * tiles_x + tx, wgt);
+        }
+      }
+    }
+    boxes[ro] = box;
+  }
+  if (one_src) {
+    __syncthreads();
+    // the block's source image: that of its first ray
+    const int ov = (int)((ro_first / R) % ovn);
+    const size_t bv = ro_first / ((size_t)R * ovn);
+    const int v = (int)(bv % dm.v);
+    uint32_t* tw = tile_work + (bv - v + (ov < v ? ov : ov + 1)) * (size_t)tiles;
+    for (int i = threadIdx.x; i < tiles; i += blockDim.x)
+      if (hist[i] != 0u) atomicAdd(tw + i, hist[i]);
+  }
+}
+
+// Longest-first block order for the gather: a coarse (power-of-two buckets) descending sort of
+// the n_work tiles by their work estimate, one block.  The order inside a bucket depends on the
+// atomics' arrival order; it changes the schedule, never a result.
+__global__ void __launch_bounds__(1024)
+epipolar_tile_order_kernel(int n_work, const uint32_t* __restrict__ tile_work,
+                           uint32_t* __restrict__ order) {
+  __shared__ uint32_t count[32], base[32];
+  if (threadIdx.x < 32) count[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_work; i += blockDim.x)
+    atomicAdd(&count[31 - __clz((int)(tile_work[i] | 1u))], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int bkt = 31; bkt >= 0; --bkt) { base[bkt] = run; run += count[bkt]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_work; i += blockDim.x) {
+    const int bkt = 31 - __clz((int)(tile_work[i] | 1u));
+    order[atomicAdd(&base[bkt], 1u)] = (uint32_t)i;
+  }
 }
 
 template <int CPL> struct LaneVec;
@@ -1001,14 +1071,17 @@ template <int CPL, int TS>
 __global__ void __launch_bounds__(kDfWaves* kWave)
 epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
                              const uint32_t* __restrict__ boxes, const float* __restrict__ tg,
-                             float* __restrict__ dfmap) {
+                             const uint32_t* __restrict__ order, float* __restrict__ dfmap) {
   extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][TS*TS pixels + dummy][c]
   using V = typename LaneVec<CPL>::type;
   const int R = dm.h * dm.w, ovn = dm.v - 1;
   const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
-  const int per_xcd = (int)gridDim.x / 8;                       // XCD-aware order, as above
-  const int work = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
-  if (work >= n_work) return;
+  // Blocks run longest-first: the samples of converging epipolar lines pile up on one side of the
+  // image (20 to 2600 token visits per tile at the paper config) and the blocks are dispatched in
+  // index order, so the heavy tiles must not come last.  (No XCD affinity needed any more: a
+  // token's row is read by the 1-4 tiles it touches, not by every tile of its line.)
+  if ((int)blockIdx.x >= n_work) return;
+  const int work = (int)order[blockIdx.x];
   const int tile_id = work % (tiles_x * tiles_y);
   const int src_bv = work / (tiles_x * tiles_y);                // (b, source view)
   const int b = src_bv / dm.v, sv = src_bv % dm.v;
@@ -1244,17 +1317,26 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
     if (!L.attn[l] || !L.ds[l] || !L.dfbar[l] || !L.qt[l]) return PS_ERR_BAD_ARG;
   }
   const size_t n_ro = (size_t)dm.b * dm.v * dm.h * dm.w * (dm.v - 1);
-  hipLaunchKernelGGL(epipolar_ray_box_kernel, dim3((unsigned)((n_ro + 255) / 256)), dim3(256), 0,
-                     st, dm, xy, flags, boxes);
   constexpr int TS = 4;
   const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
   const int n_work = dm.b * dm.v * tiles;
+  // two passes: the words behind the n_ro boxes hold the tile work estimates and the block order
+  uint32_t* tile_work = token_grad != nullptr ? boxes + n_ro : nullptr;
+  uint32_t* order = token_grad != nullptr ? boxes + n_ro + n_work : nullptr;
+  if (tile_work != nullptr &&
+      hipMemsetAsync(tile_work, 0, (size_t)n_work * sizeof(uint32_t), st) != hipSuccess)
+    return PS_ERR_LAUNCH;
+  hipLaunchKernelGGL(epipolar_ray_box_kernel<TS>, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
+                     tile_work != nullptr ? (size_t)tiles * sizeof(uint32_t) : 0, st, dm, xy, flags,
+                     boxes, tile_work);
   dim3 g2((unsigned)((n_work + 7) / 8 * 8)), b2(kDfWaves * kWave);
   const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
   const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
   const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
   if (token_grad != nullptr) {     // two passes: token gradients once, then the tile gather
     dim3 g1((unsigned)((n_ro + 3) / 4)), b1(256);
+    hipLaunchKernelGGL(epipolar_tile_order_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_work,
+                       order);
 #define PS_TG(CPL)                                                                              \
   do {                                                                                          \
     if (n_layers == 1) hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 1>), g1, b1, 0, st,  \
@@ -1262,7 +1344,7 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
     else hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 2>), g1, b1, 0, st, dm, flags, L,  \
                             token_grad);                                                        \
     hipLaunchKernelGGL((epipolar_dfmap_gather_kernel<CPL, TS>), g2, b2, sm2, st, dm, n_work,    \
-                       xy, boxes, token_grad, dfmap);                                           \
+                       xy, boxes, token_grad, order, dfmap);                                    \
   } while (0)
     if (dm.c <= 64) PS_TG(1); else if (dm.c <= 128) PS_TG(2); else PS_TG(4);
 #undef PS_TG

@@ -387,6 +387,12 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* d, int32_t n_layers, const fl
   return check_launch();
 }
 
+size_t ps_epipolar_ray_box_words(const PsEpipolarDesc* d) {
+  if (!epi_ok(d)) return 0;
+  const size_t tiles = (size_t)((d->w + 3) / 4) * ((d->h + 3) / 4);
+  return (size_t)d->b * d->v * (d->v - 1) * d->h * d->w + 2 * (size_t)d->b * d->v * tiles;
+}
+
 size_t ps_epipolar_token_grad_floats(const PsEpipolarDesc* d) {
   if (!epi_ok(d)) return 0;
   return (size_t)d->b * d->v * (d->v - 1) * d->h * d->w * d->s * d->c;

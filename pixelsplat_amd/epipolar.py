@@ -247,7 +247,8 @@ class FeatureGradBatch:
     def flush(self, desc, fmap, xy, flags, c):
         lib = _lib.load()
         total = None
-        boxes = torch.empty((flags.numel(),), dtype=torch.int32, device=fmap.device)
+        boxes = torch.empty((max(flags.numel(), lib.ps_epipolar_ray_box_words(C.byref(desc))),),
+                            dtype=torch.int32, device=fmap.device)
         while self.pending:
             group, self.pending = (self.pending[:self.MAX_PER_LAUNCH],
                                    self.pending[self.MAX_PER_LAUNCH:])
