@@ -1107,15 +1107,44 @@ epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ 
     const size_t bv = (size_t)b * dm.v + v;
     const size_t ro0 = (bv * ovn + ov) * R;
     for (int chunk0 = 0; chunk0 < R; chunk0 += kDfChunk) {
-      // 1. cull: lanes <-> rays (identical to the single-pass kernel)
+      // 1. cull, lanes <-> rays, in two sweeps so that the loads do not wait for each other:
+      //    (a) the packed boxes of the wave's rays against the tile, four 64-ray groups per trip
+      //        (four independent loads in flight), candidates appended to the wave's list;
+      //    (b) the exact segment-vs-tile test on the candidates, 64 at a time: ONE round of
+      //        sample-position loads per 64 candidates instead of one per 64 rays.
+      //    (The single-pass kernel tests group by group: 16 x 2 dependent latencies per view.)
       int count = 0;
-      for (int r0 = chunk0 + wv * kWave; r0 < min(chunk0 + kDfChunk, R); r0 += kDfWaves * kWave) {
-        const int r = r0 + lane;
-        const uint32_t box = r < R ? boxes[ro0 + r] : 0x00FF00FFu;
-        const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
-        bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
-        if (hit) {
-          const size_t so = (ro0 + r) * dm.s;
+      const int r_end = min(chunk0 + kDfChunk, R);
+      for (int r0 = chunk0 + wv * kWave; r0 < r_end; r0 += 4 * kDfWaves * kWave) {
+        uint32_t bx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * kDfWaves * kWave + lane;
+          bx[u] = r < r_end ? boxes[ro0 + r] : 0x00FF00FFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * kDfWaves * kWave + lane;
+          const uint32_t box = bx[u];
+          const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
+          const bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+          const uint64_t m = __ballot(hit);
+          if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)(r - chunk0);
+          count += __popcll(m);
+        }
+      }
+      wave_lds_sync();
+      const int n_cand = count;
+      count = 0;
+      for (int c0 = 0; c0 < n_cand; c0 += kWave) {
+        const bool on = c0 + lane < n_cand;
+        const int rl = on ? (int)list[c0 + lane] : 0;
+        bool hit = false;
+        if (on) {
+          // exact test: a sample touches the tile iff its pixel position lies in
+          // [tx0 - 1, tx1 + 1) x [ty0 - 1, ty1 + 1); the samples lie on the segment between
+          // the first and the last one (Liang-Barsky clip, 0.02 px of slack for rounding)
+          const size_t so = (ro0 + chunk0 + rl) * dm.s;
           const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * so);
           const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (so + dm.s - 1));
           const Corner ca = corner_of(p0.x, p0.y, dm.w, dm.h), cb = corner_of(p1.x, p1.y, dm.w, dm.h);
@@ -1133,8 +1162,10 @@ epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ 
           hit = ta <= tb;
         }
         const uint64_t m = __ballot(hit);
-        if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)(r - chunk0);
+        wave_lds_sync();               // every lane has read its candidate: compact in place
+        if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)rl;
         count += __popcll(m);
+        wave_lds_sync();
       }
       wave_lds_sync();
       if (count == 0) continue;
