@@ -267,7 +267,8 @@ def test_epipolar_transformer_module_vs_reference_golden(gpu_device, name, v, oc
 
 
 @pytest.mark.parametrize("m,n,k", [(512, 128, 4096), (128, 512, 1000), (80, 128, 777), (128, 80, 258),
-                                   (4, 4, 1), (130, 260, 513)])
+                                   (4, 4, 1), (130, 260, 513), (576, 128, 57344), (1300, 644, 300),
+                                   (128, 592, 12289)])
 def test_gemm_tn_splitk(gpu_device, m, n, k):
     """ps_gemm_tn_f32 (fp32 MFMA, split-k, fixed-order reduction) against a float64 product:
     within fp32 accumulation error, and bit-reproducible."""
