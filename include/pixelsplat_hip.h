@@ -480,6 +480,12 @@ int ps_invert_cameras(int32_t n, const float* c2w, const float* k, float* w2c, f
 size_t ps_gemm_tn_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int ps_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda, const float* b,
                    int32_t ldb, float* c, void* workspace, size_t workspace_bytes, void* stream);
+/* Same product plus, as a by-product of the operand stream, colsum_a[m] = sum_k a[k][m] (m floats;
+ * may be NULL): with a = dY this is the bias gradient of the Linear layer (autograd of
+ * nn.Linear(inner_dim, dim) at attention.py:45), which otherwise costs a pass of its own over dY. */
+int ps_gemm_tn_colsum_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda,
+                          const float* b, int32_t ldb, float* c, float* colsum_a, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* Profiling aid for bench.py (process-global, off by default; the only mutable global in the
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents

@@ -70,7 +70,7 @@ EXPORTS = [
     "ps_raster_forward_render", "ps_raster_forward_colors", "ps_raster_forward_bins", "ps_raster_forward_tiles", "ps_raster_backward", "ps_raster_backward_prepare",
     "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
     "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
-    "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_epipolar_token_grad_floats", "ps_epipolar_ray_box_words", "ps_epipolar_feature_grad_two_pass", "ps_gaussian_adapter_views",
+    "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_gemm_tn_colsum_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_epipolar_token_grad_floats", "ps_epipolar_ray_box_words", "ps_epipolar_feature_grad_two_pass", "ps_gaussian_adapter_views",
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
     "ps_gaussian_head_forward", "ps_gaussian_head_backward",
     "ps_depth_sampler_forward", "ps_depth_sampler_backward",
@@ -205,6 +205,8 @@ def load():
     lib.ps_gemm_tn_workspace_bytes.restype = C.c_size_t
     lib.ps_gemm_tn_f32.argtypes = [C.c_int32] * 3 + [vp, C.c_int32, vp, C.c_int32, vp, vp, C.c_size_t, vp]
     lib.ps_gemm_tn_f32.restype = C.c_int
+    lib.ps_gemm_tn_colsum_f32.argtypes = [C.c_int32] * 3 + [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.c_size_t, vp]
+    lib.ps_gemm_tn_colsum_f32.restype = C.c_int
     lib.ps_raster_check.argtypes = [C.POINTER(PsRasterDesc), vp, C.c_size_t,
                                     C.POINTER(C.c_uint64), vp]
     lib.ps_raster_check.restype = C.c_int

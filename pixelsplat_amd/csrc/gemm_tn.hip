@@ -76,7 +76,8 @@ static GemmPlan gemm_tn_plan(int M, int N, int K) {
 template <int PF, bool XCD_AWARE, int WPB>
 __global__ void __launch_bounds__(kWave * WPB)
 gemm_tn_partial_kernel(int M, int N, int K, int rows, int parts, const float* __restrict__ A, int lda,
-                       const float* __restrict__ B, int ldb, float* __restrict__ partial) {
+                       const float* __restrict__ B, int ldb, float* __restrict__ partial,
+                       float* __restrict__ colpart) {
   const int tiles_n = (N + kGemmTile - 1) / kGemmTile, tiles_m = (M + kGemmTile - 1) / kGemmTile;
   int tile, part;
   if (XCD_AWARE) {
@@ -125,6 +126,9 @@ gemm_tn_partial_kernel(int M, int N, int K, int rows, int parts, const float* __
   // HBM miss behind, so a slot is refilled right after its MFMAs were issued and is not looked
   // at again for PF - 1 steps (~1000 MFMA cycles each).  The scheduling barrier keeps that order.
   float4 ra[PF], rb[PF];
+  // by-product: the column sums of A over this slice (the bias gradient sum_k dY[k][m] when
+  // A = dY); four adds per k-step that issue under the MFMAs
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     ra[u] = load_a(k_begin + 2 * u + kk);
@@ -140,6 +144,7 @@ gemm_tn_partial_kernel(int M, int N, int K, int rows, int parts, const float* __
       const float4 a = ra[u], b = rb[u];
       const float av[4] = {live ? a.x : 0.f, live ? a.y : 0.f, live ? a.z : 0.f, live ? a.w : 0.f};
       const float bv[4] = {b.x, b.y, b.z, b.w};
+      cs.x += av[0]; cs.y += av[1]; cs.z += av[2]; cs.w += av[3];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -150,6 +155,10 @@ gemm_tn_partial_kernel(int M, int N, int K, int rows, int parts, const float* __
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+
+  // column sums: the waves of the first tile column park [slice][k parity][M] partial sums
+  if (colpart != nullptr && n0 == 0 && ma < M)
+    *reinterpret_cast<float4*>(colpart + ((size_t)chunk * 2 + kk) * M + ma) = cs;
 
   // store of the tile rows {4 r + i}: MFMA (i, j), register e of lane l is row
   // 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32 of the 32x32 block, i.e. tile row 4 * row + i,
@@ -232,13 +241,19 @@ gemm_tn_partial_kernel(int M, int N, int K, int rows, int parts, const float* __
 }
 
 // 64 elements x 4 chunk groups per block; each thread keeps 4 loads in flight, the four
-// group sums are combined in a fixed order
+// group sums are combined in a fixed order.  Blocks past `blocks1` do the same for the second
+// job (the column sums), so that the by-product costs no launch.
 __global__ void __launch_bounds__(256)
 gemm_tn_reduce_kernel(int n_elem, int n_chunks, const float* __restrict__ partial,
-                      float* __restrict__ C) {
+                      float* __restrict__ C, int blocks1, int n_elem2, int n_chunks2,
+                      const float* __restrict__ partial2, float* __restrict__ C2) {
   __shared__ float part[4][64];
+  int blk = blockIdx.x;
+  if (blk >= blocks1) {
+    blk -= blocks1; n_elem = n_elem2; n_chunks = n_chunks2; partial = partial2; C = C2;
+  }
   const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
+  const int e = blk * 64 + el;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < n_elem) {
     int c = g;
@@ -257,17 +272,20 @@ gemm_tn_reduce_kernel(int n_elem, int n_chunks, const float* __restrict__ partia
 
 size_t gemm_tn_workspace_bytes(int M, int N, int K) {
   const GemmPlan p = gemm_tn_plan(M, N, K);
-  return (size_t)p.parts * M * N * sizeof(float);
+  // partial tiles + the column-sum partials [slice][k parity][M] (slices incl. the empty ones of
+  // the last block)
+  return ((size_t)p.parts * M * N + (size_t)p.parts * p.wpb * 2 * M) * sizeof(float);
 }
 
 int launch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                   float* C, float* workspace, hipStream_t st) {
+                   float* C, float* colsum_a, float* workspace, hipStream_t st) {
   // float4 loads/stores need 16-byte aligned rows
   if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
       ((uintptr_t)workspace & 15))
     return PS_ERR_UNSUPPORTED;
   const GemmPlan p = gemm_tn_plan(M, N, K);
   const dim3 grid((unsigned)p.blocks), block(kWave * p.wpb);
+  float* colpart = colsum_a ? workspace + (size_t)p.parts * M * N : nullptr;
 #define PS_GEMM_TN_LAUNCH(PF, XCD, WPB)                                                            \
   do {                                                                                             \
     constexpr size_t lds = WPB > 1 ? (size_t)4 * 3 * 2 * 4 * kWave * sizeof(float4) : 0;           \
@@ -275,7 +293,7 @@ int launch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B,
         (const void*)gemm_tn_partial_kernel<PF, XCD, WPB>,                                         \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); (void)lds_ok_;       \
     hipLaunchKernelGGL((gemm_tn_partial_kernel<PF, XCD, WPB>), grid, block, lds, st, M, N, K,      \
-                       p.rows, p.parts, A, lda, B, ldb, workspace);                                \
+                       p.rows, p.parts, A, lda, B, ldb, workspace, colpart);                       \
   } while (0)
   switch (gemm_tn_variant()) {
     case 0: PS_GEMM_TN_LAUNCH(kGemmPrefetch, false, 1); break;
@@ -284,8 +302,10 @@ int launch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B,
     default: PS_GEMM_TN_LAUNCH(8, true, 4);
   }
 #undef PS_GEMM_TN_LAUNCH
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((M * N + 63) / 64)), dim3(256), 0, st,
-                     M * N, p.parts, workspace, C);
+  const int blocks1 = (M * N + 63) / 64, blocks2 = colsum_a ? (M + 63) / 64 : 0;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)(blocks1 + blocks2)), dim3(256), 0, st,
+                     M * N, p.parts, workspace, C, blocks1, M, p.parts * p.wpb * 2,
+                     (const float*)colpart, colsum_a);
   return PS_OK;
 }
 

@@ -676,15 +676,22 @@ size_t ps_gemm_tn_workspace_bytes(int32_t m, int32_t n, int32_t k) {
   return (m > 0 && n > 0 && k > 0) ? gemm_tn_workspace_bytes(m, n, k) : 0;
 }
 
-int ps_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda, const float* b,
-                   int32_t ldb, float* c, void* workspace, size_t workspace_bytes, void* stream) {
+int ps_gemm_tn_colsum_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda,
+                          const float* b, int32_t ldb, float* c, float* colsum_a, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || !workspace || lda < m || ldb < n)
     return PS_ERR_BAD_ARG;
   if (workspace_bytes < gemm_tn_workspace_bytes(m, n, k)) return PS_ERR_WORKSPACE;
   Scope sc(G_GEMM_TN, (hipStream_t)stream);
-  if (int rc = launch_gemm_tn(m, n, k, a, lda, b, ldb, c, (float*)workspace, (hipStream_t)stream))
+  if (int rc = launch_gemm_tn(m, n, k, a, lda, b, ldb, c, colsum_a, (float*)workspace,
+                              (hipStream_t)stream))
     return rc;
   return check_launch();
+}
+
+int ps_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float* a, int32_t lda, const float* b,
+                   int32_t ldb, float* c, void* workspace, size_t workspace_bytes, void* stream) {
+  return ps_gemm_tn_colsum_f32(m, n, k, a, lda, b, ldb, c, nullptr, workspace, workspace_bytes, stream);
 }
 
 int ps_raster_check(const PsRasterDesc* d, const void* state, size_t state_bytes,

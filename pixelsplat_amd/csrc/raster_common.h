@@ -233,8 +233,9 @@ int launch_layer_norm_backward(int rows, int dim, const float* x, const float* g
 void launch_camera_inverse(int n, const float* c2w, const float* k, float* w2c, float* k_inv,
                            hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N, int K);
+// colsum_a (may be null): sum_k A[k][m], M floats
 int launch_gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                   float* C, float* workspace, hipStream_t st);
+                   float* C, float* colsum_a, float* workspace, hipStream_t st);
 
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }

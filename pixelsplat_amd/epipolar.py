@@ -92,26 +92,31 @@ def gather_features(fmap_nhwc: Tensor, geo: EpipolarGeometry) -> Tensor:
     return out
 
 
-def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
+def gemm_tn(a: Tensor, b: Tensor, colsum: bool = False):
     """a [k, m], b [k, n] (fp32, row-major, last dim contiguous) -> a^T b [m, n] with the split-k
-    MFMA kernel (ps_gemm_tn_f32); deterministic."""
+    MFMA kernel (ps_gemm_tn_colsum_f32); deterministic.  colsum=True also returns a.sum(0) [m],
+    gathered from the operand stream of the same kernel."""
     lib = _lib.load()
     k, m = a.shape
     n = b.shape[1]
     if n % 4:                      # the kernel works on groups of 4 columns
-        return gemm_tn(a, torch.nn.functional.pad(b, (0, -n % 4)))[:, :n]
+        r = gemm_tn(a, torch.nn.functional.pad(b, (0, -n % 4)), colsum)
+        return (r[0][:, :n], r[1]) if colsum else r[:, :n]
     if m % 4:
-        return gemm_tn(torch.nn.functional.pad(a, (0, -m % 4)), b)[:m]
+        r = gemm_tn(torch.nn.functional.pad(a, (0, -m % 4)), b, colsum)
+        return (r[0][:m], r[1][:m]) if colsum else r[:m]
     if a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
         a = a.contiguous()
     if b.stride(1) != 1 or b.stride(0) % 4 or b.data_ptr() % 16:
         b = b.contiguous()
     c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    cs = torch.empty((m,), dtype=torch.float32, device=a.device) if colsum else None
     ws_bytes = lib.ps_gemm_tn_workspace_bytes(m, n, k)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=a.device)
-    _lib.check(lib.ps_gemm_tn_f32(m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(c), _p(ws),
-                                  C.c_size_t(ws_bytes), _stream()), "ps_gemm_tn_f32")
-    return c
+    _lib.check(lib.ps_gemm_tn_colsum_f32(m, n, k, _p(a), a.stride(0), _p(b), b.stride(0), _p(c),
+                                         _p(cs), _p(ws), C.c_size_t(ws_bytes), _stream()),
+               "ps_gemm_tn_colsum_f32")
+    return (c, cs) if colsum else c
 
 
 class _RayLinear(torch.autograd.Function):
@@ -129,11 +134,18 @@ class _RayLinear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dy @ w if ctx.needs_input_grad[0] else None
-        dw = None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            ok = dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0
-            dw = gemm_tn(dy, x) if ok else dy.T @ x
-        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            if dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0:
+                if want_db:      # the bias gradient falls out of the dY stream of the same kernel
+                    dw, db = gemm_tn(dy, x, colsum=True)
+                else:
+                    dw = gemm_tn(dy, x)
+            else:
+                dw = dy.T @ x
+        if want_db and db is None:
+            db = dy.sum(0)
         return dx, dw, db
 
 

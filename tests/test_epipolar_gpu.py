@@ -288,6 +288,12 @@ def test_gemm_tn_splitk(gpu_device, m, n, k):
     c3 = gemm_tn(wide[:, 4:4 + m], b.to(gpu_device))
     ref3 = wide[:, 4:4 + m].cpu().double().T @ b.double()
     assert (c3.cpu().double() - ref3).abs().max().item() < 2e-6 * k ** 0.5 * 4
+    # the column-sum by-product (the bias gradient when a = dY): same product bit for bit, the
+    # sums against float64, reproducible
+    c4, s4 = gemm_tn(a.to(gpu_device), b.to(gpu_device), colsum=True)
+    c5, s5 = gemm_tn(a.to(gpu_device), b.to(gpu_device), colsum=True)
+    assert torch.equal(c4, c1) and torch.equal(s4, s5) and s4.shape == (m,)
+    assert (s4.cpu().double() - a.double().sum(0)).abs().max().item() < 2e-6 * k ** 0.5 * 4
 
 
 @pytest.mark.parametrize("v,c", [(2, 128), (3, 32)])
