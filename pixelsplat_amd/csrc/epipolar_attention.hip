@@ -159,6 +159,20 @@ epipolar_gather_kernel(AttnDims dm, const float* __restrict__ fmap,
 //   F  lanes <-> channels       context accumulation; weights via v_readlane
 // The feature rows use a stride of S4 quads with S4 = 8 (mod 16): the 16 lanes of one pass
 // of a 128-bit LDS read then cover all 64 banks.
+template <int CPL> struct LaneVec;
+template <> struct LaneVec<1> { using type = float; };
+template <> struct LaneVec<2> { using type = float2; };
+template <> struct LaneVec<4> { using type = float4; };
+
+template <int CPL>
+__device__ __forceinline__ void load_cpl(const float* __restrict__ p, float* out) {
+  using V = typename LaneVec<CPL>::type;
+  const V q = *reinterpret_cast<const V*>(p);
+  const float* f = reinterpret_cast<const float*>(&q);
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) out[i] = f[i];
+}
+
 constexpr int kChunk = 8;       // tokens per chunk
 constexpr int kUPL = 3;         // encoding dims per lane in phase D (P <= 24)
 
@@ -244,39 +258,6 @@ __device__ __forceinline__ bool ray_setup(const AttnDims& dm, float* smem, RayCt
   return true;
 }
 
-// phase A: token records of the whole ray
-__device__ __forceinline__ void stage_records(const AttnDims& dm, const RayCtx& k, int lane,
-                                              const float* __restrict__ xy,
-                                              const uint8_t* __restrict__ flags,
-                                              const float* __restrict__ rd) {
-  const int R = dm.h * dm.w;
-  for (int t = lane; t < k.T; t += kWave) {
-    const int si = t / k.ovn, ov = t - si * k.ovn;
-    const size_t ro = (k.bv * k.ovn + ov) * R + k.r;
-    const size_t so = ro * dm.s + si;
-    const int src = (int)k.bbase + (ov < k.v ? ov : ov + 1);
-    const bool ok = flags[ro] & 1;
-    const float2 p = *reinterpret_cast<const float2*>(xy + 2 * so);
-    const Corner cq = corner_of(p.x, p.y, dm.w, dm.h);
-    const bool xin0 = cq.x0 >= 0 && cq.x0 < dm.w, xin1 = cq.x0 + 1 >= 0 && cq.x0 + 1 < dm.w;
-    const bool yin0 = cq.y0 >= 0 && cq.y0 < dm.h, yin1 = cq.y0 + 1 >= 0 && cq.y0 + 1 < dm.h;
-    const int xa = min(max(cq.x0, 0), dm.w - 1), xb = min(max(cq.x0 + 1, 0), dm.w - 1);
-    const int ya = min(max(cq.y0, 0), dm.h - 1), yb = min(max(cq.y0 + 1, 0), dm.h - 1);
-    const int base = src * R;
-    int4 off = make_int4(base + ya * dm.w + xa, base + ya * dm.w + xb, base + yb * dm.w + xa,
-                         base + yb * dm.w + xb);
-    float4 wt;
-    wt.x = (ok && xin0 && yin0) ? (1.f - cq.wx) * (1.f - cq.wy) : 0.f;
-    wt.y = (ok && xin1 && yin0) ? cq.wx * (1.f - cq.wy) : 0.f;
-    wt.z = (ok && xin0 && yin1) ? (1.f - cq.wx) * cq.wy : 0.f;
-    wt.w = (ok && xin1 && yin1) ? cq.wx * cq.wy : 0.f;
-    *reinterpret_cast<int4*>(k.tokS + t * 8) = off;
-    *reinterpret_cast<float4*>(k.tokS + t * 8 + 4) = wt;
-    k.rdS[t] = rd[so];
-  }
-  wave_lds_sync();
-}
-
 // phases B, C: encodings and gathered features of tokens [t0, t0 + 8) into the chunk buffers
 template <int CK>
 __device__ __forceinline__ void stage_chunk(const AttnDims& dm, const RayCtx& k, int lane, int t0,
@@ -338,24 +319,111 @@ struct QueryRegs {
   float u[kMaxHeads][kUPL];
 };
 
-__device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, int lane,
-                                           const float* __restrict__ qrow, int hs_q,
-                                           const float* __restrict__ urow, int hs_u,
-                                           QueryRegs& Q) {
-  for (int hh = 0; hh < kMaxHeads; ++hh)      // absent heads are zero rows: no per-head branches
-    for (int i = lane * 4; i < dm.c; i += kWave * 4)
-      *reinterpret_cast<float4*>(k.qS + hh * dm.c + i) =
-          hh < k.H ? *reinterpret_cast<const float4*>(qrow + hh * hs_q + i)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int j = lane & 7;
+// Phase A (token records of the whole ray: corner offsets + bilinear weights [T][8], relative
+// disparity [T]) and the "query" of phase D (channel part to LDS [h][c] -- the 8 token lanes of
+// a slice read the same address, a broadcast; encoding part in registers: lane = 8 tl + j holds
+// the dims j, j + 8, ... of urow for every head) in ONE memory round trip.  Written as two plain
+// staging loops the compiler emitted one s_waitcnt vmcnt(0) per load (flags -> xy -> rd, then one
+// per head row of the query): 8 dependent round trips before the first token chunk, on a kernel
+// whose waves spend 40-60 % of their life in s_waitcnt (SQ_WAIT_ANY).  Every address below depends on the ray index only, so all loads --
+// token records of lanes' tokens t = lane, lane + 64, the H query rows, the encoding rows and
+// (backward) the ray's attention weights -- are issued back to back, unconditionally (clamped
+// addresses, values masked afterwards), and consumed after that.
+template <bool WITH_AW>
+__device__ __forceinline__ void ray_prologue(const AttnDims& dm, const RayCtx& k, int lane,
+                                             const float* __restrict__ xy,
+                                             const uint8_t* __restrict__ flags,
+                                             const float* __restrict__ rd,
+                                             const float* __restrict__ qrow, int hs_q,
+                                             const float* __restrict__ urow, int hs_u,
+                                             QueryRegs& Q, const float* __restrict__ attn_row,
+                                             float (&aw)[2][kMaxHeads]) {
+  const int R = dm.h * dm.w;
+  // ---- issue ----
+  uint32_t fl[2];
+  float2 pxy[2];
+  float rdv[2];
+  int srcv[2];
+  // (no branch in here, not even a wave-uniform "T > 64": a value that is live across a branch
+  // is materialised at the join, i.e. waited for, and the batch falls apart again)
 #pragma unroll
-  for (int hh = 0; hh < kMaxHeads; ++hh) {
-    const int hs = hh < k.H ? hh : 0;
+  for (int u = 0; u < 2; ++u) {
+    const int t = lane + u * kWave;
+    const int tc = t < k.T ? t : 0;
+    const int si = tc / k.ovn, ov = tc - si * k.ovn;
+    const size_t ro = (k.bv * k.ovn + ov) * R + k.r;
+    const size_t so = ro * dm.s + si;
+    srcv[u] = (int)k.bbase + (ov < k.v ? ov : ov + 1);
+    fl[u] = flags[ro];
+    pxy[u] = *reinterpret_cast<const float2*>(xy + 2 * so);
+    rdv[u] = rd[so];
+  }
+  const int qi = lane * 4;
+  const bool qin = qi < dm.c;                      // c <= 256: one float4 per lane and head row
+  float4 qv[kMaxHeads];
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh)
+    qv[hh] = *reinterpret_cast<const float4*>(qrow + (hh < k.H ? hh : 0) * hs_q + (qin ? qi : 0));
+  const int j = lane & 7;
+  // (urow is a valid row even for P = 0: the host passes the query row then)
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh)
 #pragma unroll
     for (int i = 0; i < kUPL; ++i) {
       const int p = j + 8 * i;
-      Q.u[hh][i] = (p < k.P && hh < k.H) ? urow[hs * hs_u + p] : 0.f;
+      Q.u[hh][i] = urow[(hh < k.H ? hh : 0) * hs_u + (p < k.P ? p : 0)];
     }
+  if (WITH_AW) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh) {
+        const int t = lane + u * kWave;
+        const bool ok = t < k.T && hh < k.H;
+        aw[u][hh] = attn_row[(size_t)(ok ? hh : 0) * k.T + (ok ? t : 0)];
+      }
+  }
+  // ---- consume ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = lane + u * kWave;
+    if (t < k.T) {
+      const bool ok = fl[u] & 1u;
+      const Corner cq = corner_of(pxy[u].x, pxy[u].y, dm.w, dm.h);
+      const bool xin0 = cq.x0 >= 0 && cq.x0 < dm.w, xin1 = cq.x0 + 1 >= 0 && cq.x0 + 1 < dm.w;
+      const bool yin0 = cq.y0 >= 0 && cq.y0 < dm.h, yin1 = cq.y0 + 1 >= 0 && cq.y0 + 1 < dm.h;
+      const int xa = min(max(cq.x0, 0), dm.w - 1), xb = min(max(cq.x0 + 1, 0), dm.w - 1);
+      const int ya = min(max(cq.y0, 0), dm.h - 1), yb = min(max(cq.y0 + 1, 0), dm.h - 1);
+      const int base = srcv[u] * R;
+      const int4 off = make_int4(base + ya * dm.w + xa, base + ya * dm.w + xb,
+                                 base + yb * dm.w + xa, base + yb * dm.w + xb);
+      float4 wt;
+      wt.x = (ok && xin0 && yin0) ? (1.f - cq.wx) * (1.f - cq.wy) : 0.f;
+      wt.y = (ok && xin1 && yin0) ? cq.wx * (1.f - cq.wy) : 0.f;
+      wt.z = (ok && xin0 && yin1) ? (1.f - cq.wx) * cq.wy : 0.f;
+      wt.w = (ok && xin1 && yin1) ? cq.wx * cq.wy : 0.f;
+      *reinterpret_cast<int4*>(k.tokS + t * 8) = off;
+      *reinterpret_cast<float4*>(k.tokS + t * 8 + 4) = wt;
+      k.rdS[t] = rdv[u];
+    }
+  }
+  if (qin) {
+#pragma unroll
+    for (int hh = 0; hh < kMaxHeads; ++hh)       // absent heads are zero rows: no per-head branches
+      *reinterpret_cast<float4*>(k.qS + hh * dm.c + qi) =
+          hh < k.H ? qv[hh] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh)
+#pragma unroll
+    for (int i = 0; i < kUPL; ++i)
+      Q.u[hh][i] = (j + 8 * i < k.P && hh < k.H) ? Q.u[hh][i] : 0.f;
+  if (WITH_AW) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hh = 0; hh < kMaxHeads; ++hh)
+        aw[u][hh] = (lane + u * kWave < k.T && hh < k.H) ? aw[u][hh] : 0.f;
   }
   wave_lds_sync();
 }
@@ -364,8 +432,8 @@ __device__ __forceinline__ void load_query(const AttnDims& dm, const RayCtx& k, 
 // tl = lane / 8, valid in the lanes with j == 7
 template <int CK>
 __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k, int lane, int t0,
-                                             const QueryRegs& Q, const float* __restrict__ erow,
-                                             int hs_e, float (&out)[kMaxHeads]) {
+                                             const QueryRegs& Q, const float (&ev)[kMaxHeads],
+                                             bool with_view_term, float (&out)[kMaxHeads]) {
   const int tl = lane >> 3, j = lane & 7;
   const float* frow = k.featS + tl * k.fs;
   // even / odd components accumulate in the two halves of a register pair: the packed FMAs
@@ -400,15 +468,28 @@ __device__ __forceinline__ void chunk_scores(const AttnDims& dm, const RayCtx& k
 #pragma unroll
     for (int hh = 0; hh < kMaxHeads; ++hh) acc[hh] = fmaf(Q.u[hh][i], pe, acc[hh]);
   }
-  if (erow != nullptr && j == 0) {
-    const int ov = min(t0 + tl, k.T - 1) % k.ovn;
 #pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh)
-      if (hh < k.H) acc[hh] += erow[hh * hs_e + ov];
-  }
+  for (int hh = 0; hh < kMaxHeads; ++hh)      // view term, once per token: lane j == 0
+    acc[hh] += (with_view_term && j == 0 && hh < k.H) ? ev[hh] : 0.f;
   group8_sum4(acc[0], acc[1], acc[2], acc[3]);
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) out[hh] = acc[hh];
+}
+
+// the per-view term erow_{h, ov(t)} of the chunk's tokens, fetched BEFORE the chunk's gathers so
+// that its latency runs under theirs.  Raw values: the load is unconditional (`safe` is any
+// readable row when there is no view term) and chunk_scores() masks it -- a select here would be
+// a use, i.e. a wait, in front of the gathers.
+__device__ __forceinline__ void load_view_term(const RayCtx& k, int lane, int t0,
+                                               const float* __restrict__ erow, int hs_e,
+                                               const float* __restrict__ safe,
+                                               float (&ev)[kMaxHeads]) {
+  const int tl = lane >> 3;
+  const int ov = min(t0 + tl, k.T - 1) % k.ovn;
+  const float* src = erow != nullptr ? erow : safe;
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh)
+    ev[hh] = src[(erow != nullptr && hh < k.H) ? hh * hs_e + ov : 0];
 }
 
 // phase F accumulators: lanes <-> channels
@@ -479,10 +560,11 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   if (!ray_setup(dm, smem, k)) return;
   const int lane = threadIdx.x & 63;
   const size_t rh = (size_t)k.ray * k.H;
-  stage_records(dm, k, lane, xy, flags, rd);
   QueryRegs Q;
   const size_t ray = (size_t)k.ray;
-  load_query(dm, k, lane, qt + ray * dm.ld_q, dm.hs_q, u + ray * dm.ld_u, dm.hs_u, Q);
+  float aw_unused[2][kMaxHeads];
+  ray_prologue<false>(dm, k, lane, xy, flags, rd, qt + ray * dm.ld_q, dm.hs_q, u + ray * dm.ld_u,
+                      dm.hs_u, Q, nullptr, aw_unused);
   const float* erow = e ? e + ray * dm.ld_e : nullptr;
 
   ContextRegs<CK> A;
@@ -493,9 +575,11 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   const bool score_lane = (lane & 7) == 7;
 
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
+    float ev[kMaxHeads];
+    load_view_term(k, lane, t0, erow, dm.hs_e, qt + ray * dm.ld_q, ev);
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float sc[kMaxHeads];
-    chunk_scores<CK>(dm, k, lane, t0, Q, erow, dm.hs_e, sc);
+    chunk_scores<CK>(dm, k, lane, t0, Q, ev, erow != nullptr, sc);
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
     float mx[kMaxHeads];
@@ -564,30 +648,26 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   if (!ray_setup(dm, smem, k)) return;
   const int lane = threadIdx.x & 63;
   const size_t rh = (size_t)k.ray * k.H;
-  stage_records(dm, k, lane, xy, flags, rd);
   QueryRegs Q;
   const size_t ray = (size_t)k.ray;
-  load_query(dm, k, lane, dfbar + ray * dm.ld_f, dm.hs_f, dpbar + ray * dm.ld_p, dm.hs_p, Q);
+  // the ray's attention weights, lanes <-> tokens (T <= 128: two per lane), loaded ONCE, with
+  // everything else the ray needs up front (ray_prologue): a load inside the chunk loop put one
+  // more dependent global latency into every chunk
+  float aw[2][kMaxHeads];
+  ray_prologue<true>(dm, k, lane, xy, flags, rd, dfbar + ray * dm.ld_f, dm.hs_f,
+                     dpbar + ray * dm.ld_p, dm.hs_p, Q, attn + rh * k.T, aw);
   const float* erow = dabar ? dabar + ray * dm.ld_a : nullptr;
 
   ContextRegs<CK> A;
   A.clear();
   float dot[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
   const bool score_lane = (lane & 7) == 7;
-  // the ray's attention weights, lanes <-> tokens (T <= 128: two per lane), loaded ONCE up front:
-  // a load inside the chunk loop put one more dependent global latency into every chunk
-  float aw[2][kMaxHeads];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int hh = 0; hh < kMaxHeads; ++hh) {
-      const int t = lane + u * kWave;
-      aw[u][hh] = (t < k.T && hh < k.H) ? attn[(rh + hh) * k.T + t] : 0.f;
-    }
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
+    float ev[kMaxHeads];
+    load_view_term(k, lane, t0, erow, dm.hs_a, dfbar + ray * dm.ld_f, ev);
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float da[kMaxHeads];
-    chunk_scores<CK>(dm, k, lane, t0, Q, erow, dm.hs_a, da);
+    chunk_scores<CK>(dm, k, lane, t0, Q, ev, erow != nullptr, da);
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
 #pragma unroll
@@ -606,26 +686,37 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
     chunk_context<CK, WITH_O>(dm, k, lane, t0, da, A);
     wave_lds_sync();
   }
-  wave_sum4_to_lane63(dot[0], dot[1], dot[2], dot[3]);
+  // the forward outputs that close the expressions: every load issued before the first use
+  // (one dependent load -> store pair per head and output was 12 round trips at the end of
+  // every wave)
   const int c0 = lane * CPL;
+  const bool c_in = c0 < dm.c, p_in = lane < k.P, o_in = de != nullptr && lane < k.ovn;
+  float fb[kMaxHeads][CPL], pb[kMaxHeads], ab[kMaxHeads];
+  const float* ab_src = abar != nullptr ? abar : pbar;      // any readable row when absent
+#pragma unroll
+  for (int hh = 0; hh < kMaxHeads; ++hh) {
+    const int hs = hh < k.H ? hh : 0;
+    load_cpl<CPL>(fbar + ray * dm.ld_f + hs * dm.hs_f + (c_in ? c0 : 0), fb[hh]);
+    pb[hh] = pbar[ray * dm.ld_p + hs * dm.hs_p + (p_in ? lane : 0)];
+    ab[hh] = ab_src[abar != nullptr ? ray * dm.ld_a + hs * dm.hs_a + (o_in ? lane : 0)
+                                    : ray * dm.ld_p];
+  }
+  wave_sum4_to_lane63(dot[0], dot[1], dot[2], dot[3]);
 #pragma unroll
   for (int hh = 0; hh < kMaxHeads; ++hh) {
     if (hh >= k.H) break;
     const float d = lane_bcast(dot[hh], 63);
-    if (c0 < dm.c) {
+    if (c_in) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i)
-        dqt[ray * dm.ld_q + hh * dm.hs_q + c0 + i] =
-            scale * (A.f[hh][i] - d * fbar[ray * dm.ld_f + hh * dm.hs_f + c0 + i]);
+        dqt[ray * dm.ld_q + hh * dm.hs_q + c0 + i] = scale * (A.f[hh][i] - d * fb[hh][i]);
     }
-    if (lane < k.P)
-      du[ray * dm.ld_u + hh * dm.hs_u + lane] =
-          scale * (A.p[hh] - d * pbar[ray * dm.ld_p + hh * dm.hs_p + lane]);
-    if (de != nullptr && lane < k.ovn) {
+    if (p_in) du[ray * dm.ld_u + hh * dm.hs_u + lane] = scale * (A.p[hh] - d * pb[hh]);
+    if (o_in) {
       // abar is only produced when the view embedding exists; otherwise it is the softmax mass
       // of the single other view, i.e. one
-      const float ab = abar ? abar[ray * dm.ld_a + hh * dm.hs_a + lane] : 1.0f;
-      de[ray * dm.ld_e + hh * dm.hs_e + lane] = scale * (A.o[hh] - d * ab);
+      de[ray * dm.ld_e + hh * dm.hs_e + lane] =
+          scale * (A.o[hh] - d * (abar != nullptr ? ab[hh] : 1.0f));
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -745,20 +836,6 @@ epipolar_tile_order_kernel(int n_work, const uint32_t* __restrict__ tile_work,
     const int bkt = 31 - __clz((int)(tile_work[i] | 1u));
     order[atomicAdd(&base[bkt], 1u)] = (uint32_t)i;
   }
-}
-
-template <int CPL> struct LaneVec;
-template <> struct LaneVec<1> { using type = float; };
-template <> struct LaneVec<2> { using type = float2; };
-template <> struct LaneVec<4> { using type = float4; };
-
-template <int CPL>
-__device__ __forceinline__ void load_cpl(const float* __restrict__ p, float* out) {
-  using V = typename LaneVec<CPL>::type;
-  const V q = *reinterpret_cast<const V*>(p);
-  const float* f = reinterpret_cast<const float*>(&q);
-#pragma unroll
-  for (int i = 0; i < CPL; ++i) out[i] = f[i];
 }
 
 __device__ __forceinline__ int lane_bcast_i(int v, int lane) {
