@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpixelsplat_hip.so")
+# PIXELSPLAT_HIP_LIB: another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("PIXELSPLAT_HIP_LIB") or os.path.join(HERE, "libpixelsplat_hip.so")
 
 PS_SH_GK3, PS_SH_G3K = 0, 1
 PS_COV_6, PS_COV_33 = 0, 1

@@ -50,17 +50,35 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
   }
   float gm[3] = {0.f, 0.f, 0.f}, gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f;
 
-  for (int j = 0; j < vps; ++j) {
+  // radius, rect and clamp bits of four views at a time, branch free (clamped view index): read
+  // one after the other inside the view loop (radius -> rect -> slots -> clamp bits) they were
+  // four dependent memory round trips per view, sixteen per thread at four views
+  const uint8_t* cbp = color_grads ? clamp_bits : reinterpret_cast<const uint8_t*>(radii);
+  for (int j0 = 0; j0 < vps; j0 += 4) {
+   int32_t rad4[4];
+   uint2 rect4[4];
+   uint32_t cb4[4];
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+     const size_t vgc = (size_t)(s * vps + min(j0 + u, vps - 1)) * G + g;
+     rad4[u] = radii[vgc];
+     rect4[u] = rects[vgc];
+     cb4[u] = cbp[vgc];
+   }
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int j = j0 + u;
+    if (j >= vps) break;
     const int v = s * vps + j;
     const size_t vg = (size_t)v * G + g;
-    const bool vis = radii[vg] > 0;
+    const bool vis = rad4[u] > 0;
     float gr[kGradFloats];
 #pragma unroll
     for (int c = 0; c < kGradFloats; ++c) gr[c] = 0.f;
     if (vis) {
       // Gaussians touching <= 4 tiles: sum their private (Gaussian, tile) slots in tile order
       // (deterministic); larger ones were accumulated with atomics into grad2d
-      const uint2 r = rects[vg];
+      const uint2 r = rect4[u];
       const uint32_t area = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
       if (area <= (uint32_t)kInvSlots && (H + kTile - 1) / kTile <= 16383) {
         // its private slots (one per tile of the rect, row-major; the tile backward wrote every
@@ -70,18 +88,22 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
         const float* sp0 = tile_grads + vg * (size_t)(kInvSlots * kSlotFloats);
 #pragma unroll
         for (int k = 0; k < kInvSlots; ++k) {
-          const bool on = (uint32_t)k < area;
-          const float* sp = sp0 + (on ? k : 0) * kSlotFloats;
+          // unconditional loads from a clamped slot, masked when summed: `on ? tg[0] : 0` is a
+          // load the compiler may not speculate, so it became a branch per slot with a wait at
+          // every join -- the "all loads first" of the comment above did not survive
+          const float* sp = sp0 + ((uint32_t)k < area ? k : 0) * kSlotFloats;
           const float4* tg = reinterpret_cast<const float4*>(sp);
-          a0[k] = on ? tg[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-          a1[k] = on ? tg[1] : make_float4(0.f, 0.f, 0.f, 0.f);
-          a2[k] = on ? sp[8] : 0.f;
+          a0[k] = tg[0];
+          a1[k] = tg[1];
+          a2[k] = sp[8];
         }
 #pragma unroll
         for (int k = 0; k < kInvSlots; ++k) {
-          gr[0] += a0[k].x; gr[1] += a0[k].y; gr[2] += a0[k].z; gr[3] += a0[k].w;
-          gr[4] += a1[k].x; gr[5] += a1[k].y; gr[6] += a1[k].z; gr[7] += a1[k].w;
-          gr[8] += a2[k];
+          if ((uint32_t)k < area) {
+            gr[0] += a0[k].x; gr[1] += a0[k].y; gr[2] += a0[k].z; gr[3] += a0[k].w;
+            gr[4] += a1[k].x; gr[5] += a1[k].y; gr[6] += a1[k].z; gr[7] += a1[k].w;
+            gr[8] += a2[k];
+          }
         }
       } else {
         const float* gi = grad2d + vg * kGradFloats;
@@ -103,7 +125,7 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
     }
     if (!vis) continue;
     if (color_grads) {   // SH path: dL/dRGB with the forward's clamp applied, 12-byte rows
-      const uint32_t cb = clamp_bits[vg];
+      const uint32_t cb = cb4[u];
       float* o = color_grads + vg * 3;
       o[0] = (cb & 1u) ? 0.f : gr[6];
       o[1] = (cb & 2u) ? 0.f : gr[7];
@@ -192,6 +214,7 @@ geometry_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
     }
     gm[0] += scale * gmx; gm[1] += scale * gmy; gm[2] += scale * gmz;
     gop += g_op;
+   }
   }
 
   float* om = dL_dmeans + sg * 3;

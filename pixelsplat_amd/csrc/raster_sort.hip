@@ -27,13 +27,18 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
     if (t < 256) h[t] = 0;
     __syncthreads();
     const uint32_t* k = keys + (size_t)v * G;
+    // all loads first, branch free (clamped index): a load inside `if (p < limit)` is waited
+    // for at the end of its branch, i.e. kSortItems dependent round trips per thread
+    uint32_t key[kSortItems];
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
       const int p = base + i * kSortThreads + t;
-      if (p < limit) {
-        const uint32_t key = k[p];
-        if (!FIRST || key != kCulledKey) atomicAdd(&h[(key >> shift) & 0xFFu], 1u);
-      }
+      key[i] = k[p < limit ? p : base];
+    }
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+      const int p = base + i * kSortThreads + t;
+      if (p < limit && (!FIRST || key[i] != kCulledKey)) atomicAdd(&h[(key[i] >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
   }
@@ -110,14 +115,29 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
   uint2 rc[LAST ? kSortItems : 1];
   const uint64_t lt = lanemask_lt();
+  // Every global load of the block's items is issued before the ranking starts, branch free
+  // (clamped index, masked afterwards): keys and values in one round trip, the rect gathers of
+  // the last pass in a second one that runs under the ranking.  Loading inside the per-item
+  // loop made each item wait for its own loads: kSortItems dependent round trips per wave.
+  const int p_safe = blk * kSortChunk;               // < limit (checked above)
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int p = start + i * kWave + lane;
+    const int pc = p < limit ? p : p_safe;
+    key[i] = keys_in[vo + pc];
+    val[i] = IOTA_VALS ? (uint32_t)pc : vals_in[vo + pc];
+  }
+  // the block's digit offsets (used after the ranking by threads 0..255; every thread loads)
+  const uint32_t digit_base = block_hist[((size_t)v * nblk + blk) * 256 + (t & 255)];
+  if (LAST) {
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) rc[i] = rects[vo + val[i]];
+  }
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     const int p = start + i * kWave + lane;
     bool valid = p < limit;
-    key[i] = valid ? keys_in[vo + p] : 0u;
     if (IOTA_VALS) valid = valid && key[i] != kCulledKey;
-    val[i] = valid ? (IOTA_VALS ? (uint32_t)p : vals_in[vo + p]) : 0u;
-    if (LAST) rc[i] = valid ? rects[vo + val[i]] : make_uint2(0u, 0u);
     const uint32_t dg = (key[i] >> shift) & 0xFFu;
     uint64_t mask = __ballot(valid);
 #pragma unroll
@@ -138,7 +158,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   }
   __syncthreads();
   if (t < 256) {
-    uint32_t b = block_hist[((size_t)v * nblk + blk) * 256 + t];
+    uint32_t b = digit_base;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { base[i][t] = b; b += cnt[i][t]; }
   }
