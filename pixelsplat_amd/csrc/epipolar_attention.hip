@@ -329,7 +329,7 @@ struct QueryRegs {
 // token records of lanes' tokens t = lane, lane + 64, the H query rows, the encoding rows and
 // (backward) the ray's attention weights -- are issued back to back, unconditionally (clamped
 // addresses, values masked afterwards), and consumed after that.
-template <bool WITH_AW>
+template <bool WITH_AW, int NT>     // NT = token rows per lane: 1 (T <= 64) or 2 (T <= 128)
 __device__ __forceinline__ void ray_prologue(const AttnDims& dm, const RayCtx& k, int lane,
                                              const float* __restrict__ xy,
                                              const uint8_t* __restrict__ flags,
@@ -340,14 +340,14 @@ __device__ __forceinline__ void ray_prologue(const AttnDims& dm, const RayCtx& k
                                              float (&aw)[2][kMaxHeads]) {
   const int R = dm.h * dm.w;
   // ---- issue ----
-  uint32_t fl[2];
-  float2 pxy[2];
-  float rdv[2];
-  int srcv[2];
+  uint32_t fl[NT];
+  float2 pxy[NT];
+  float rdv[NT];
+  int srcv[NT];
   // (no branch in here, not even a wave-uniform "T > 64": a value that is live across a branch
   // is materialised at the join, i.e. waited for, and the batch falls apart again)
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NT; ++u) {
     const int t = lane + u * kWave;
     const int tc = t < k.T ? t : 0;
     const int si = tc / k.ovn, ov = tc - si * k.ovn;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void ray_prologue(const AttnDims& dm, const RayCtx& k
     }
   if (WITH_AW) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int hh = 0; hh < kMaxHeads; ++hh) {
         const int t = lane + u * kWave;
@@ -385,7 +385,7 @@ __device__ __forceinline__ void ray_prologue(const AttnDims& dm, const RayCtx& k
   }
   // ---- consume ----
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NT; ++u) {
     const int t = lane + u * kWave;
     if (t < k.T) {
       const bool ok = fl[u] & 1u;
@@ -423,7 +423,7 @@ __device__ __forceinline__ void ray_prologue(const AttnDims& dm, const RayCtx& k
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int hh = 0; hh < kMaxHeads; ++hh)
-        aw[u][hh] = (lane + u * kWave < k.T && hh < k.H) ? aw[u][hh] : 0.f;
+        aw[u][hh] = (u < NT && lane + u * kWave < k.T && hh < k.H) ? aw[u][hh] : 0.f;
   }
   wave_lds_sync();
 }
@@ -546,7 +546,7 @@ __device__ __forceinline__ void chunk_context(const AttnDims& dm, const RayCtx& 
   }
 }
 
-template <int CK, bool WITH_O>
+template <int CK, bool WITH_O, int NT>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
                              const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -563,7 +563,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   QueryRegs Q;
   const size_t ray = (size_t)k.ray;
   float aw_unused[2][kMaxHeads];
-  ray_prologue<false>(dm, k, lane, xy, flags, rd, qt + ray * dm.ld_q, dm.hs_q, u + ray * dm.ld_u,
+  ray_prologue<false, NT>(dm, k, lane, xy, flags, rd, qt + ray * dm.ld_q, dm.hs_q, u + ray * dm.ld_u,
                       dm.hs_u, Q, nullptr, aw_unused);
   const float* erow = e ? e + ray * dm.ld_e : nullptr;
 
@@ -632,7 +632,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
 // so the weighted sums use w_t = a_t da_t, known per chunk, and the forward outputs
 // (fbar, pbar, abar) close the expression -- no second gather.
 // ------------------------------------------------------------------------------------
-template <int CK, bool WITH_O>
+template <int CK, bool WITH_O, int NT>
 __global__ void __launch_bounds__(kAttnWaves* kWave)
 epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
                               const float* __restrict__ xy, const uint8_t* __restrict__ flags,
@@ -654,7 +654,7 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   // everything else the ray needs up front (ray_prologue): a load inside the chunk loop put one
   // more dependent global latency into every chunk
   float aw[2][kMaxHeads];
-  ray_prologue<true>(dm, k, lane, xy, flags, rd, dfbar + ray * dm.ld_f, dm.hs_f,
+  ray_prologue<true, NT>(dm, k, lane, xy, flags, rd, dfbar + ray * dm.ld_f, dm.hs_f,
                      dpbar + ray * dm.ld_p, dm.hs_p, Q, attn + rh * k.T, aw);
   const float* erow = dabar ? dabar + ray * dm.ld_a : nullptr;
 
@@ -1369,17 +1369,20 @@ int launch_epipolar_attn_forward(const AttnDims& dm, const float* fmap, const fl
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
   const size_t sm = attn_smem(dm);
-#define PS_GO2(L, O)                                                                            \
+  const bool two_rows = dm.s * (dm.v - 1) > kWave;   // tokens per ray > 64: two token rows per lane
+#define PS_GO2(L, O, N)                                                                         \
   do {                                                                                          \
     static const bool lds_ok_ = (hipFuncSetAttribute(                                           \
-        (const void*)epipolar_attn_forward_kernel<L, O>,                                        \
+        (const void*)epipolar_attn_forward_kernel<L, O, N>,                                     \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;          \
-    hipLaunchKernelGGL((epipolar_attn_forward_kernel<L, O>), grid, block, sm, st, dm, fmap, xy, \
-                       flags, rd, qt, u, e, scale, fbar, pbar, abar, attn);                     \
+    hipLaunchKernelGGL((epipolar_attn_forward_kernel<L, O, N>), grid, block, sm, st, dm, fmap,  \
+                       xy, flags, rd, qt, u, e, scale, fbar, pbar, abar, attn);                 \
   } while (0)
-#define PS_GO(L) do { if (e != nullptr) PS_GO2(L, true); else PS_GO2(L, false); } while (0)
+#define PS_GO1(L, O) do { if (two_rows) PS_GO2(L, O, 2); else PS_GO2(L, O, 1); } while (0)
+#define PS_GO(L) do { if (e != nullptr) PS_GO1(L, true); else PS_GO1(L, false); } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO
+#undef PS_GO1
 #undef PS_GO2
   return PS_OK;
 }
@@ -1394,18 +1397,21 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
   const size_t rays = (size_t)dm.b * dm.v * dm.h * dm.w;
   dim3 grid((unsigned)((rays + kAttnWaves - 1) / kAttnWaves)), block(kAttnWaves * kWave);
   const size_t sm = attn_smem(dm);
-#define PS_GO2(L, O)                                                                            \
+  const bool two_rows = dm.s * (dm.v - 1) > kWave;   // tokens per ray > 64: two token rows per lane
+#define PS_GO2(L, O, N)                                                                         \
   do {                                                                                          \
     static const bool lds_ok_ = (hipFuncSetAttribute(                                           \
-        (const void*)epipolar_attn_backward_kernel<L, O>,                                       \
+        (const void*)epipolar_attn_backward_kernel<L, O, N>,                                    \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); (void)lds_ok_;          \
-    hipLaunchKernelGGL((epipolar_attn_backward_kernel<L, O>), grid, block, sm, st, dm, fmap,    \
+    hipLaunchKernelGGL((epipolar_attn_backward_kernel<L, O, N>), grid, block, sm, st, dm, fmap, \
                        xy, flags, rd, attn, fbar, pbar, abar, dfbar, dpbar, dabar, scale, dqt,  \
                        du, de, ds);                                                             \
   } while (0)
-#define PS_GO(L) do { if (de != nullptr) PS_GO2(L, true); else PS_GO2(L, false); } while (0)
+#define PS_GO1(L, O) do { if (two_rows) PS_GO2(L, O, 2); else PS_GO2(L, O, 1); } while (0)
+#define PS_GO(L) do { if (de != nullptr) PS_GO1(L, true); else PS_GO1(L, false); } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO
+#undef PS_GO1
 #undef PS_GO2
   return PS_OK;
 }
