@@ -41,16 +41,25 @@ def enable(path: str | None = None) -> bool:
         return False
 
 
-if __name__ == "__main__":   # python -m pixelsplat_amd.gemm_tuning --tune : regenerate the table
+def main(argv: list) -> None:
+    """python -m pixelsplat_amd.gemm_tuning --tune [--out NAME] [-- bench.py arguments]:
+    regenerates a table on the GPU by running bench.py with TunableOp tuning switched on."""
     import subprocess
     import sys
 
-    if "--tune" in sys.argv:
-        out = os.path.join(HERE, "_tuned.csv")
-        env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1",
-                   PYTORCH_TUNABLEOP_FILENAME=out, PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS="15",
-                   PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS="3", PIXELSPLAT_NO_TUNED_GEMMS="1")
-        root = os.path.dirname(os.path.dirname(HERE))
-        subprocess.check_call([sys.executable, os.path.join(root, "bench.py"), "--steps", "3",
-                               "--warmup", "1", "--no-cpu-baseline"], env=env)
-        print("wrote", out.replace(".csv", "0.csv"), "- review and rename it to", TABLE)
+    if "--tune" not in argv:
+        print(main.__doc__)
+        return
+    # arguments after "--" go to bench.py (another configuration: --context-views 3 --batch 4);
+    # --out NAME picks the file to write (default _tuned -> _tuned0.csv)
+    extra = argv[argv.index("--") + 1:] if "--" in argv else []
+    name = argv[argv.index("--out") + 1] if "--out" in argv else "_tuned"
+    out = os.path.join(HERE, name + ".csv")
+    env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1",
+               PYTORCH_TUNABLEOP_FILENAME=out, PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS="15",
+               PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS="3", PIXELSPLAT_NO_TUNED_GEMMS="1")
+    root = os.path.dirname(os.path.dirname(HERE))
+    subprocess.check_call([sys.executable, os.path.join(root, "bench.py"), "--steps", "3",
+                           "--warmup", "1", "--no-cpu-baseline", "--launch", "eager"] + extra,
+                          env=env)
+    print("wrote", out.replace(".csv", "0.csv"), "- review and merge it into", TABLE)
