@@ -25,7 +25,11 @@ namespace ps {
 
 constexpr int kBatch = 64;
 constexpr int kQB = 128;            // ring B capacity (>= 63 + 64), power of two
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;      // forward: tiles (waves) per block
+// backward: one wave per block -- a new block of four needs four free wave slots on one CU,
+// i.e. it waits for four waves of that CU to retire; with single-wave blocks a slot is refilled
+// the moment it frees (tiles_backward 1.868 -> 1.825 ms; the forward does not care: +0.5 %)
+constexpr int kWavesPerBlockBwd = 1;
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct WaveLds {
@@ -447,7 +451,7 @@ __device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float 
 //   3  = 1 held to 3 waves/SIMD (168 VGPRs, no spill)                            2.17 ms
 // WPS: waves per SIMD the register allocation is held to (4 -> 128 VGPRs; 3 -> 168)
 template <int VAR, int WPS>
-__global__ void __launch_bounds__(kWavesPerBlock* kWave, WPS)
+__global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, WPS)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_ranges,
@@ -456,13 +460,13 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ n_contrib,
                       const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
                       float* __restrict__ grad2d, float* __restrict__ tile_grads) {
-  __shared__ WaveLdsBwd lds_all[kWavesPerBlock];
+  __shared__ WaveLdsBwd lds_all[kWavesPerBlockBwd];
   const int G = d.n_gaussians, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
   const int tiles = gx * gy;
   const int V = d.n_scenes * d.views_per_scene;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot_global = blockIdx.x * kWavesPerBlock + w;
+  const int slot_global = blockIdx.x * kWavesPerBlockBwd + w;
   if (slot_global >= V * tiles) return;
   const int tile_global = (int)tile_order[slot_global];   // longest lists are launched first
   WaveLdsBwd& lds = lds_all[w];
@@ -749,7 +753,7 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
-  dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
+  dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
   static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 4; }();
 #define PS_BWD(V, W)                                                                             \
   hipLaunchKernelGGL((tiles_backward_kernel<V, W>), grid, block, 0, st, d, records, tile_order,   \
