@@ -30,6 +30,7 @@ constexpr int kWavesPerBlock = 4;      // forward: tiles (waves) per block
 // i.e. it waits for four waves of that CU to retire; with single-wave blocks a slot is refilled
 // the moment it frees (tiles_backward 1.868 -> 1.825 ms; the forward does not care: +0.5 %)
 constexpr int kWavesPerBlockBwd = 1;
+constexpr int kSlotVec = kSlotFloats / 4;   // float4 units per gradient slot
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct WaveLds {
@@ -483,7 +484,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   // geometry backward still sums the private slot of every (Gaussian, tile) pair of a small
   // Gaussian, so the slots of those entries are cleared here (nothing is memset)
   const uint32_t c_max = tile_end[tile_global];
-  float4* const slots = reinterpret_cast<float4*>(tile_grads) + vo * (kInvSlots * 3);
+  float4* const slots = reinterpret_cast<float4*>(tile_grads) + vo * (kInvSlots * kSlotVec);
   {
     uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
     if (l_count > capacity - l_start) l_count = capacity - l_start;
@@ -492,8 +493,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       const uint32_t pk = __float_as_uint(recs[(size_t)id * kRecFloats + 7]);
       if (pk & kSmallFlag) {
         const uint32_t kk = (ty - ((pk >> 15) & 0x3FFFu)) * (((pk >> 29) & 3u) + 1u) + (tx - (pk & 0x7FFFu));
-        float4* tg = slots + ((size_t)id * kInvSlots + kk) * 3;
+        float4* tg = slots + ((size_t)id * kInvSlots + kk) * kSlotVec;
         tg[0] = tg[1] = tg[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);   // 64-byte slots: whole line
       }
     }
   }
@@ -563,8 +565,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         const uint32_t kk = (ty - ((pk >> 15) & 0x3FFFu)) * (((pk >> 29) & 3u) + 1u) + (tx - (pk & 0x7FFFu));
         target = id * (uint32_t)kInvSlots + kk;
         if (!keep) {   // cannot reach any quadrant: never blended, its slot is still summed
-          float4* tg = slots + (size_t)target * 3;
+          float4* tg = slots + (size_t)target * kSlotVec;
           tg[0] = tg[1] = tg[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       q2 = make_float4(r2.z, __uint_as_float(top - lane), __uint_as_float(qm | small),
@@ -720,10 +723,11 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       if (__float_as_uint(q2.z) & 16u) {
         // private slot of this (Gaussian, tile): plain 16-byte stores, summed later in a fixed
         // order by the geometry backward (no atomics, deterministic)
-        float4* tg = slots + (size_t)__float_as_uint(q2.w) * 3;
+        float4* tg = slots + (size_t)__float_as_uint(q2.w) * kSlotVec;
         tg[0] = hit ? make_float4(o0, o1, o2, o3) : make_float4(0.f, 0.f, 0.f, 0.f);
         tg[1] = hit ? make_float4(o4, gs[5], gs[6], gs[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
         tg[2] = make_float4(hit ? gs[8] : 0.f, 0.f, 0.f, 0.f);
+        if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
       } else if (hit) {
         float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
         atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
