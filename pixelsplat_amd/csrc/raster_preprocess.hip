@@ -1,14 +1,18 @@
-// Per-Gaussian preprocess (forward), two kernels:
+// Per-Gaussian preprocess (forward):
 //
+//   fused     (default, <= 4 views per scene) one lane per (view, Gaussian) pair, a wave per 16
+//             Gaussians: geometry, then -- if any lane of the wave survived the cull -- the SH slab
+//             through LDS and the colour; the 48-byte record is written once.  See the comment at
+//             preprocess_fused_kernel.
 //   geometry  one thread per scene Gaussian, looping over the scene's views: frustum cull,
 //             projection, EWA 2-D covariance, conic, 3-sigma radius, tile rect, depth key.
 //             {mean, cov, opacity} are read once per scene, not once per view (the reference
-//             materialises v copies: decoder_splatting_cuda.py:53-56).  Small register
-//             footprint -> full occupancy; HBM-bound.
-//   colour    one wave per 64 Gaussians: the wave stages their SH coefficients (64 x 3K
+//             materialises v copies: decoder_splatting_cuda.py:53-56).
+//   colour    one wave per 32 Gaussians: the wave stages their SH coefficients (32 x 3K
 //             contiguous floats) in LDS with coalesced 16-byte loads -- 300 of the 340 input
 //             bytes per Gaussian -- then evaluates the degree<=4 colour for every view in
 //             which the Gaussian survived the cull.  Lane stride 3K is odd => conflict-free.
+//             (geometry + colour: the path for colors_precomp, deferred colours, > 4 views.)
 //
 // Semantics: SURVEY.md Appendix A.1 -- what `GaussianRasterizer.forward` computes per
 // Gaussian for the call at /root/reference/src/model/decoder/cuda_splatting.py:117-124.
