@@ -420,3 +420,55 @@ def test_more_than_32_views_per_scene(gpu_device):
         assert np.array_equal(radii[v], st.radii)
         ok = R.ambiguity_mask(st) == 0
         assert np.abs(img[v] - st.image).max(0)[ok].max() <= IMG_TOL
+
+
+@pytest.mark.parametrize("n_scenes,vps,n_g", [(2, 3, 1003), (3, 2, 37), (2, 4, 1030)])
+def test_fused_preprocess_ragged_sizes(gpu_device, n_scenes, vps, n_g):
+    """The fused geometry + colour kernel (a wave = 16 Gaussians x up to 4 views) at sizes that are
+    not multiples of anything: a tail wave (G % 16 != 0), SH slabs that are not 16-byte aligned
+    (scene s > 0 with G % 4 != 0: the dword staging path), idle view lanes (2 or 3 views per
+    scene).  Radii, images and every gradient against the oracle, view by view."""
+    import types
+
+    from pixelsplat_amd.decoder import render_cuda
+
+    dev, hw = gpu_device, (48, 64)
+    ctx, tgt, g_all, _ = make_workload(n_scenes, (32, 32), v_ctx=2, v_tgt=vps, seed=21 + n_g)
+    g = types.SimpleNamespace(means=g_all.means[:, :n_g].contiguous(),
+                              covariances=g_all.covariances[:, :n_g].contiguous(),
+                              harmonics=g_all.harmonics[:, :n_g].contiguous(),
+                              opacities=g_all.opacities[:, :n_g].contiguous())
+    V = n_scenes * vps
+    leaves = [t.to(dev).requires_grad_(True) for t in (g.means, g.covariances, g.harmonics, g.opacities)]
+    img, aux = render_cuda(
+        tgt.extrinsics.reshape(V, 4, 4).to(dev), tgt.intrinsics.reshape(V, 3, 3).to(dev),
+        tgt.near.reshape(V).to(dev), tgt.far.reshape(V).to(dev), hw, torch.zeros(V, 3, device=dev),
+        *leaves, views_per_scene=vps, return_aux=True)
+    dL = torch.from_numpy(np.random.default_rng(n_g).normal(size=(V, 3) + hw).astype(np.float32))
+    (img * dL.to(dev)).sum().backward()
+    img = img.detach().cpu().numpy()
+    vp = aux["view_params"].cpu().numpy()
+    radii = aux["radii"].cpu().numpy()
+    row, col = np.triu_indices(3)
+    n_vis = 0
+    for s in range(n_scenes):
+        ref = dict(means=np.zeros((n_g, 3)), cov=np.zeros((n_g, 3, 3)), sh=np.zeros((n_g, 3, 25)),
+                   op=np.zeros(n_g))
+        for j in range(vps):
+            v = s * vps + j
+            st = R.forward(H=hw[0], W=hw[1], **oracle_view_inputs(g, tgt, s, j, view_params=vp[v]))
+            assert np.array_equal(radii[v], st.radii), f"radii scene {s} view {j}"
+            n_vis += int((st.radii > 0).sum())
+            ok = R.ambiguity_mask(st) == 0
+            assert np.abs(img[v] - st.image).max(0)[ok].max() <= IMG_TOL
+            gr = R.backward(st, dL[v].numpy())
+            scale = float(vp[v, 40])
+            ref["means"] += gr["means3D"] * scale
+            cov_g = np.zeros((n_g, 3, 3))
+            cov_g[:, row, col] = gr["cov6"]
+            ref["cov"] += cov_g * scale ** 2
+            ref["sh"] += gr["sh"].transpose(0, 2, 1)
+            ref["op"] += gr["opacity"]
+        for leaf, key in zip(leaves, ("means", "cov", "sh", "op")):
+            _grad_close(leaf.grad[s].cpu().numpy(), ref[key], f"{key} scene {s}")
+    assert n_vis > 0.2 * V * n_g, "scene not exercised: almost nothing visible"
