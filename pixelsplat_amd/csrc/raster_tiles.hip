@@ -21,6 +21,10 @@
 
 #include <cstdlib>
 
+#ifndef PS_ABLATE
+#define PS_ABLATE 0   // 1..3: timing experiments that drop part of a tile kernel's work (results invalid)
+#endif
+
 namespace ps {
 
 constexpr int kBatch = 64;
@@ -243,7 +247,11 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   // one ring entry against the (up to four) quadrants it can reach
   auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
     const uint32_t hidx = __float_as_uint(q2.y);
+#if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
+    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
+#else
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
@@ -586,7 +594,11 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   auto entry = [&](uint32_t j, const float4 q0, const float4 q1, const float4 q2) {
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
+#if PS_ABLATE == 2   // timing experiment: no per-pixel math (and so no reduction)
+      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
+#else
       const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+#endif
       float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
       float s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
       bool any = false;
@@ -662,7 +674,12 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         }
       }
       }
+#if PS_ABLATE == 1   // timing experiment: per-pixel math kept, the nine wave sums and their hand-over dropped
+      asm volatile("" :: "v"(Mx), "v"(My), "v"(Mxx), "v"(Mxy), "v"(Myy), "v"(s_op), "v"(s_r), "v"(s_g), "v"(s_b));
+      if (false) {
+#else
       if (__any(any)) {
+#endif
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         float r1, r2;
         wave_sum9_rows(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);
