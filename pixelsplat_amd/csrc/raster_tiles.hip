@@ -125,15 +125,17 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, f
 // ------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// VAR 0: the round-1 inner loop (explicitly rotated LDS prefetch, `live` flags, termination test
-// after every entry).  VAR 1 (default): fewer wave instructions per (pixel, entry) pair --
+// Inner loop (the result of the round-2 A/B series, profiles/r2_tiles_variants_ab.txt; the superseded
+// variants are in the history before this commit):
 //   * the transmittance carries the "finished" state in its sign (T > 0: live, T < 0: the pixel
 //     stopped and -T is its final value), so there is no separate flag to test, mask and update;
 //   * power and the (T (1 - a), T a) pair are written on 2-vectors -> v_pk_add / v_pk_mul;
-//   * the record of entry j is read from LDS where it is used (the other waves of the SIMD cover
-//     the latency) instead of being prefetched into a second register set and moved;
-//   * "is every pixel finished?" is asked once per 8 entries, not per entry.
-template <int VAR>
+//   * two entries per trip, each one's record read from LDS while the other is blended (the latency
+//     is hidden without moving a prefetched record between registers);
+//   * "is every pixel finished?" is asked once per 8 entries, not per entry;
+//   * the refine's two dependent global latencies (list -> record gather) are off the wave's critical
+//     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
+//     is refined and blended.
 __global__ void __launch_bounds__(kWavesPerBlock* kWave)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ tile_order,
@@ -178,69 +180,8 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min, t_min = d.t_min;
   bool all_done = !__any(live[0] | live[1] | live[2] | live[3]);
 
-  // refine list entries [first, first + m): lane i takes entry first + i
-  auto refine = [&](uint32_t first, uint32_t m) {
-    bool keep = false;
-    float4 q0, q1, q2;
-    if ((uint32_t)lane < m) {
-      const uint32_t id = list[first + lane];
-      const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
-      const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
-      const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
-      const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
-      keep = qm != 0u;
-      q0 = make_float4(r0.x, r0.y, A, B);
-      q1 = make_float4(Cq, r1.y, r2.x, r2.y);
-      q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
-    }
-    const uint64_t mask = __ballot(keep);
-    if (keep) {
-      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
-      lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
-    }
-    b_tail += (uint32_t)__popcll(mask);
-    wave_lds_sync();
-  };
-
-  auto blend = [&](uint32_t m) {
-    // software pipeline: entry j+1's record is fetched from LDS while entry j is blended
-    float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
-           n2 = lds.rec[b_head & (kQB - 1)][2];
-    for (uint32_t j = 0; j < m; ++j) {
-      const float4 q0 = n0, q1 = n1, q2 = n2;
-      {
-        const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
-        n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
-      }
-      const uint32_t hidx = __float_as_uint(q2.y);
-      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
-          const float dx = q0.x - pxf[k], dy = q0.y - pyf[k];
-          const float pw = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), q1.x * dy * dy);  // power*log2e
-          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
-          const bool ok = live[k] & (pw <= 0.f) & (alpha >= alpha_min);
-          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-          const float test_T = T[k] * (1.f - ale);
-          const bool stop = test_T < t_min;            // only possible when ale > 0
-          live[k] = live[k] & !stop;
-          const float wgt = stop ? 0.f : ale * T[k];
-          C0[k] = fmaf(q1.z, wgt, C0[k]);
-          C1[k] = fmaf(q1.w, wgt, C1[k]);
-          C2[k] = fmaf(q2.x, wgt, C2[k]);
-          T[k] = stop ? T[k] : test_T;
-          last[k] = (ok & !stop) ? hidx : last[k];
-        }
-      }
-      if (!__any(live[0] | live[1] | live[2] | live[3])) { all_done = true; break; }
-    }
-    b_head += m;
-    wave_lds_sync();
-  };
-
-  // VAR 1: Ts[k] = T while the pixel is live, -T once it has stopped (pixels outside the image
-  // start stopped); T[] / live[] above are unused then
+  // Ts[k] = T while the pixel is live, -T once it has stopped (pixels outside the image start
+  // stopped)
   float Ts[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) Ts[k] = live[k] ? 1.f : -1.f;
@@ -278,36 +219,23 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     return !__any((Ts[0] > 0.f) | (Ts[1] > 0.f) | (Ts[2] > 0.f) | (Ts[3] > 0.f));
   };
   auto blend1 = [&](uint32_t m) {
-    if (VAR == 1) {
-      for (uint32_t j = 0; j < m; ++j) {
-        const uint32_t slot = (b_head + j) & (kQB - 1);
-        process_entry(lds.rec[slot][0], lds.rec[slot][1], lds.rec[slot][2]);
-        if ((j & 7u) == 7u && every_pixel_stopped()) { all_done = true; break; }
-      }
-    } else {
-      // VAR 2: two entries per trip, each one's record read from LDS while the other is
-      // blended -- the latency is hidden without moving a prefetched record between registers
-      uint32_t slot = b_head & (kQB - 1);
-      float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-      for (uint32_t j = 0; j < m; j += 2) {
-        slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
-        const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-        process_entry(a0, a1, a2);
-        if (j + 1 >= m) break;
-        slot = (b_head + j + 2) & (kQB - 1);
-        a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-        process_entry(b0, b1, b2);
-        if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
-      }
+    uint32_t slot = b_head & (kQB - 1);
+    float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
+    for (uint32_t j = 0; j < m; j += 2) {
+      slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
+      const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
+      process_entry(a0, a1, a2);
+      if (j + 1 >= m) break;
+      slot = (b_head + j + 2) & (kQB - 1);
+      a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
+      process_entry(b0, b1, b2);
+      if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
     }
     b_head += m;
     wave_lds_sync();
   };
 
-  if (VAR == 2) {
-    // VAR 2 also takes the refine's two dependent global latencies (list -> record gather) off
-    // the wave's critical path: the records of batch i + 1 and the list indices of batch i + 2
-    // are in flight while batch i is refined and blended
+  {
     auto gather = [&](uint32_t id, float4& r0, float4& r1, float4& r2) {
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
       r0 = r[0]; r1 = r[1]; r2 = r[2];
@@ -347,18 +275,10 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       wave_lds_sync();
       while (!all_done && b_tail - b_head >= (uint32_t)kBatch) blend1(kBatch);
     }
-  } else {
-  for (uint32_t first = 0; first < l_count && !all_done; first += kBatch) {
-    const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
-    refine(first, m);
-    while (!all_done && b_tail - b_head >= (uint32_t)kBatch) { if (VAR == 0) blend(kBatch); else blend1(kBatch); }
   }
-  }
-  if (!all_done && b_tail != b_head) { if (VAR == 0) blend(b_tail - b_head); else blend1(b_tail - b_head); }
-  if (VAR != 0) {
+  if (!all_done && b_tail != b_head) blend1(b_tail - b_head);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) T[k] = fabsf(Ts[k]);
-  }
+  for (int k = 0; k < 4; ++k) T[k] = fabsf(Ts[k]);
 
   // epilogue
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
@@ -391,16 +311,8 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  static const int variant = [] { const char* e = getenv("PS_TILES_FWD_VARIANT"); return e ? atoi(e) : 2; }();
-  if (variant == 0)
-    hipLaunchKernelGGL(tiles_forward_kernel<0>, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                       point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
-  else if (variant == 2)
-    hipLaunchKernelGGL(tiles_forward_kernel<2>, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                       point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
-  else
-    hipLaunchKernelGGL(tiles_forward_kernel<1>, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                       point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
+  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
+                     point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
 }
 
 // ------------------------------------------------------------------------------------
@@ -449,18 +361,14 @@ __device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float 
       : "+v"(r1), "+v"(r2), "+v"(i));
 }
 
-// Variants (PS_TILES_BWD_VARIANT selects; measured at BASELINE configs[1]):
-//   0  round-1 loop: LDS prefetch rotated through a second register set        2.14 ms
-//   1  record read where it is used, (dx, dy) / (B dy, C dy) as 2-vectors       2.06 ms (11 spills)
-//   2  + the per-pixel colour state and the sums kept as 2-vectors, so the packed
-//      instructions take their operands in place (no v_mov to build pairs; 116
-//      VGPRs, no spill), min(alpha_max, .) in one instruction                   1.90 ms
-//   4  (default) 2 + two entries per trip, each record read from LDS while the
-//      other entry is processed                                                 1.88 ms
-//   3  = 1 held to 3 waves/SIMD (168 VGPRs, no spill)                            2.17 ms
-// WPS: waves per SIMD the register allocation is held to (4 -> 128 VGPRs; 3 -> 168)
-template <int VAR, int WPS>
-__global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, WPS)
+// The loop is the last of the round-2 A/B series (profiles/r2_tiles_variants_ab.txt: 2.14 -> 1.82 ms at
+// BASELINE configs[1]; the superseded variants are in the history before this commit): the record is read
+// where it is used, (dx, dy) / (B dy, C dy) and the per-pixel colour state and sums are 2-vectors (the
+// packed instructions take their operands in place: no v_mov to build pairs; 126 VGPRs, no spill),
+// min(alpha_max, .) is one instruction, two entries per trip with each record read from LDS while the
+// other entry is processed.  Held to 4 waves per SIMD (128 VGPRs): 3 waves with 168 registers measured
+// slower (2.17 ms).
+__global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, 4)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_ranges,
@@ -535,17 +443,17 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
   const uint64_t lt = lanemask_lt();
   uint32_t b_head = 0, b_tail = 0;
-  // VAR 2 keeps the per-pixel colour state as 2-vectors (channels 0,1 | channel 2) so that the
-  // packed instructions take their operands in place (the auto-vectoriser packs the scalar form
-  // too, but assembles the register pairs with ~5 v_mov per pixel and entry)
+  // the per-pixel colour state as 2-vectors (channels 0,1 | channel 2) so that the packed
+  // instructions take their operands in place (the auto-vectoriser packs the scalar form too, but
+  // assembles the register pairs with ~5 v_mov per pixel and entry)
   f32x2 acc01[4], g01[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { acc01[k] = f32x2{0.f, 0.f}; g01[k] = f32x2{g0[k], g1[k]}; }
 
   // refine list entries with 1-based indices top, top-1, ..., top-m+1 (lane i takes top - i)
   // list index of this lane's entry in the batch whose first (highest) 1-based index is `top`;
-  // VAR 1 loads it one batch ahead, which takes the first of the refine's two dependent global
-  // latencies (list -> record gather) off the critical path for one register
+  // loaded one batch ahead, which takes the first of the refine's two dependent global latencies
+  // (list -> record gather) off the critical path for one register
   auto idx_of = [&](uint32_t top) {
     return (uint32_t)lane < top ? list[top - 1u - lane] : list[0];
   };
@@ -553,10 +461,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   auto refine = [&](uint32_t top, uint32_t m) {
     bool keep = false;
     float4 q0, q1, q2;
-    const uint32_t id_now = VAR == 0 ? 0u : id_ahead;
-    if (VAR != 0 && top > m) id_ahead = idx_of(top - m);
+    const uint32_t id_now = id_ahead;
+    if (top > m) id_ahead = idx_of(top - m);
     if ((uint32_t)lane < m) {
-      const uint32_t id = VAR == 0 ? list[top - 1u - lane] : id_now;
+      const uint32_t id = id_now;
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
       const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
@@ -602,7 +510,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
       float s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
       bool any = false;
-      if (VAR == 2 || VAR == 4) {
+      {
         f32x2 M1 = {0.f, 0.f}, M2 = {0.f, 0.f}, s_rg = {0.f, 0.f};   // (Mx, My) (Mxx, Mxy) (s_r, s_g)
         const f32x2 c01 = f32x2{c0, c1};
 #pragma unroll
@@ -640,39 +548,6 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
           }
         }
         Mx = M1.x; My = M1.y; Mxx = M2.x; Mxy = M2.y; s_r = s_rg.x; s_g = s_rg.y;
-      } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (qm & (1u << k)) {   // wave-uniform quadrant skip
-          const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};
-          const float dx = dd.x, dy = dd.y;
-          const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dy, dy};          // (B dy, C dy)
-          const float pw = fmaf(dx, fmaf(q0.z, dx, bc.x), dy * bc.y);
-          const float Gv = fast_exp2(pw);
-          const float alpha = fminf(alpha_max, o * Gv);
-          const bool ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
-          const float ale = ok ? alpha : 0.f;              // 0 => all updates are no-ops
-          const float oma = 1.f - ale;
-          const float rcp = __builtin_amdgcn_rcpf(oma);   // 1 ulp; exact 1 when ale == 0
-          const float Tn = T[k] * rcp;                      // T in front of this entry
-          const float d0 = c0 - acc0[k], d1 = c1 - acc1[k], d2 = c2 - acc2[k];
-          float dL_dalpha = (d0 * g0[k] + d1 * g1[k] + d2 * g2[k]) * Tn;
-          dL_dalpha = fmaf(Tfb[k], rcp, dL_dalpha);         // -T_final/(1-alpha) * bg.dL/dC
-          const float dch = ale * Tn;
-          s_r = fmaf(dch, g0[k], s_r); s_g = fmaf(dch, g1[k], s_g); s_b = fmaf(dch, g2[k], s_b);
-          const float gda = ok ? Gv * dL_dalpha : 0.f;      // G * dL/dalpha
-          s_op += gda;
-          const float q = o * gda;                          // G * dL/dG
-          const float qx = q * dx, qy = q * dy;
-          Mx += qx; My += qy;
-          Mxx = fmaf(qx, dx, Mxx); Mxy = fmaf(qx, dy, Mxy); Myy = fmaf(qy, dy, Myy);
-          T[k] = Tn;
-          acc0[k] = fmaf(ale, d0, acc0[k]);                 // alpha c + (1 - alpha) acc
-          acc1[k] = fmaf(ale, d1, acc1[k]);
-          acc2[k] = fmaf(ale, d2, acc2[k]);
-          any |= ok;
-        }
-      }
       }
 #if PS_ABLATE == 1   // timing experiment: per-pixel math kept, the nine wave sums and their hand-over dropped
       asm volatile("" :: "v"(Mx), "v"(My), "v"(Mxx), "v"(Mxy), "v"(Myy), "v"(s_op), "v"(s_r), "v"(s_g), "v"(s_b));
@@ -696,16 +571,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   };
 
   auto blend = [&](uint32_t m) {
-    if (VAR == 0) {
-      float4 n0 = lds.rec[b_head & (kQB - 1)][0], n1 = lds.rec[b_head & (kQB - 1)][1],
-             n2 = lds.rec[b_head & (kQB - 1)][2];
-      for (uint32_t j = 0; j < m; ++j) {
-        const float4 q0 = n0, q1 = n1, q2 = n2;
-        const uint32_t nslot = (b_head + j + 1) & (kQB - 1);   // (stale slot on the last trip)
-        n0 = lds.rec[nslot][0]; n1 = lds.rec[nslot][1]; n2 = lds.rec[nslot][2];
-        entry(j, q0, q1, q2);
-      }
-    } else if (VAR == 4) {
+    {
       // two entries per trip, each one's record read from LDS while the other is processed
       uint32_t slot = b_head & (kQB - 1);
       float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
@@ -717,11 +583,6 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         slot = (b_head + j + 2) & (kQB - 1);
         a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
         entry(j + 1, b0, b1, b2);
-      }
-    } else {
-      for (uint32_t j = 0; j < m; ++j) {
-        const uint32_t slot = (b_head + j) & (kQB - 1);
-        entry(j, lds.rec[slot][0], lds.rec[slot][1], lds.rec[slot][2]);
       }
     }
     wave_lds_sync();
@@ -775,17 +636,9 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles;
   dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
-  static const int variant = [] { const char* e = getenv("PS_TILES_BWD_VARIANT"); return e ? atoi(e) : 4; }();
-#define PS_BWD(V, W)                                                                             \
-  hipLaunchKernelGGL((tiles_backward_kernel<V, W>), grid, block, 0, st, d, records, tile_order,   \
-                     tile_ranges, point_list, capacity, view_params, final_T, n_contrib, tile_end, \
-                     dL_dcolor, grad2d, tile_grads)
-  if (variant == 0) PS_BWD(0, 4);
-  else if (variant == 3) PS_BWD(1, 3);
-  else if (variant == 1) PS_BWD(1, 4);
-  else if (variant == 4) PS_BWD(4, 4);
-  else PS_BWD(2, 4);
-#undef PS_BWD
+  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
+                     point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
+                     grad2d, tile_grads);
 }
 
 }  // namespace ps
