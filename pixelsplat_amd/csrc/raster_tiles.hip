@@ -24,6 +24,16 @@
 #ifndef PS_ABLATE
 #define PS_ABLATE 0   // 1..3: timing experiments that drop part of a tile kernel's work (results invalid)
 #endif
+// Experiment, not in the default build and not yet run on hardware (tools/build_variant.sh x
+// -DPS_BWD_STAGED_SUMS=1; validate with the raster GPU tests through PIXELSPLAT_HIP_LIB): the
+// backward's nine per-entry sums stop one DPP step early -- 8-lane partial sums, 24 floats per entry --
+// and are staged in LDS; the lane that finalises the entry adds the halves.  Per contributing entry
+// 9 DPP adds instead of 14, no flag traffic (the "entry contributed" bits stay in an SGPR), at the
+// price of finalising every 32 instead of every 64 entries.  Ablation says the reduction and its
+// hand-over are 26 % of the kernel.
+#ifndef PS_BWD_STAGED_SUMS
+#define PS_BWD_STAGED_SUMS 0
+#endif
 
 namespace ps {
 
@@ -40,9 +50,16 @@ constexpr float kLog2e = 1.4426950408889634f;
 struct WaveLds {
   float4 rec[kQB][3];               // {gx,gy,A,B} {C,opacity,r,g} {b,list index,quad mask,id}
 };
+#if PS_BWD_STAGED_SUMS
+constexpr int kStage = 32;              // entries per finalisation batch
+struct WaveLdsBwd : WaveLds {
+  float stage[kStage][3][8];            // per entry: r1, r2, s_b as 8-lane partial sums
+};
+#else
 struct WaveLdsBwd : WaveLds {
   float gsum[kBatch][kGradFloats + 1];  // per-entry reduced sums (+ "touched" flag)
 };
+#endif
 
 __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 #pragma unroll
@@ -361,6 +378,31 @@ __device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float 
       : "+v"(r1), "+v"(r2), "+v"(i));
 }
 
+#if PS_BWD_STAGED_SUMS
+// the nine sums down to 8-lane partials: r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]
+// (as in wave_sum9_rows), i = s_b; afterwards lanes 7 and 15 of every 16-lane row hold the sums of
+// lanes 0-7 and 8-15 of that row
+__device__ __forceinline__ void wave_sum9_partials(float a, float b, float c, float d, float e,
+                                                   float f, float g, float h, float& i, float& r1,
+                                                   float& r2) {
+  r1 = fold16(fold32(a, b), fold32(c, d));
+  r2 = fold16(fold32(e, f), fold32(g, h));
+  asm volatile(
+      "s_nop 1\n"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "s_nop 1\n"
+      : "+v"(r1), "+v"(r2), "+v"(i));
+}
+#endif
+
 // The loop is the last of the round-2 A/B series (profiles/r2_tiles_variants_ab.txt: 2.14 -> 1.82 ms at
 // BASELINE configs[1]; the superseded variants are in the history before this commit): the record is read
 // where it is used, (dx, dy) / (B dy, C dy) and the per-pixel colour state and sums are 2-vectors (the
@@ -498,6 +540,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     wave_lds_sync();
   };
 
+#if PS_BWD_STAGED_SUMS
+  uint32_t hitbits = 0;   // bit j: entry j of the finalisation batch contributed
+#endif
   // one ring entry: the pixels' updates, the nine wave sums, their hand-over through LDS
   auto entry = [&](uint32_t j, const float4 q0, const float4 q1, const float4 q2) {
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
@@ -555,6 +600,16 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
 #else
       if (__any(any)) {
 #endif
+#if PS_BWD_STAGED_SUMS
+        float r1, r2;
+        wave_sum9_partials(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);
+        if ((lane & 7) == 7) {
+          float* st = &lds.stage[j][0][lane >> 3];
+          st[0] = r1; st[8] = r2; st[16] = s_b;
+        }
+        hitbits |= 1u << j;                 // wave-uniform: stays in an SGPR
+      }
+#else
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         float r1, r2;
         wave_sum9_rows(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);
@@ -568,8 +623,60 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       } else if (lane == 63) {
         lds.gsum[j][9] = 0.f;
       }
+#endif
   };
 
+#if PS_BWD_STAGED_SUMS
+  auto blend = [&](uint32_t m) {
+    for (uint32_t base = 0; base < m; base += kStage) {
+      const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
+      hitbits = 0;
+      {
+        uint32_t slot = (b_head + base) & (kQB - 1);
+        float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
+        for (uint32_t j = 0; j < cnt; j += 2) {
+          slot = (b_head + base + j + 1) & (kQB - 1);          // (stale beyond cnt: never processed)
+          const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
+          entry(j, a0, a1, a2);
+          if (j + 1 >= cnt) break;
+          slot = (b_head + base + j + 2) & (kQB - 1);
+          a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
+          entry(j + 1, b0, b1, b2);
+        }
+      }
+      wave_lds_sync();
+      if ((uint32_t)lane < cnt) {
+        const uint32_t slot = (b_head + base + lane) & (kQB - 1);
+        const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+        const float4* sp = reinterpret_cast<const float4*>(&lds.stage[lane][0][0]);
+        const float4 u0 = sp[0], u1 = sp[1], v0 = sp[2], v1 = sp[3], w0 = sp[4], w1 = sp[5];
+        const bool hit = (hitbits >> lane) & 1u;
+        // r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]; a row = two 8-lane halves
+        const float Mx = u0.x + u0.y, Mxx = u0.z + u0.w, My = u1.x + u1.y, Mxy = u1.z + u1.w;
+        const float Myy = v0.x + v0.y, s_r = v0.z + v0.w, s_op = v1.x + v1.y, s_g = v1.z + v1.w;
+        const float s_b = ((w0.x + w0.y) + (w0.z + w0.w)) + ((w1.x + w1.y) + (w1.z + w1.w));
+        const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
+                    cz = q1.x * (-2.f / kLog2e);
+        const float o0 = (-cx * Mx - cy * My) * ddelx_dx, o1 = (-cz * My - cy * Mx) * ddely_dy;
+        const float o2 = -0.5f * Mxx, o3 = -0.5f * Mxy, o4 = -0.5f * Myy;
+        if (__float_as_uint(q2.z) & 16u) {
+          float4* tg = slots + (size_t)__float_as_uint(q2.w) * kSlotVec;
+          tg[0] = hit ? make_float4(o0, o1, o2, o3) : make_float4(0.f, 0.f, 0.f, 0.f);
+          tg[1] = hit ? make_float4(o4, s_op, s_r, s_g) : make_float4(0.f, 0.f, 0.f, 0.f);
+          tg[2] = make_float4(hit ? s_b : 0.f, 0.f, 0.f, 0.f);
+          if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (hit) {
+          float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
+          atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
+          atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, s_op);
+          atomicAdd(ga + 6, s_r); atomicAdd(ga + 7, s_g); atomicAdd(ga + 8, s_b);
+        }
+      }
+      wave_lds_sync();     // the staging rows are rewritten by the next batch
+    }
+    b_head += m;
+  };
+#else
   auto blend = [&](uint32_t m) {
     {
       // two entries per trip, each one's record read from LDS while the other is processed
@@ -616,6 +723,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     b_head += m;
     wave_lds_sync();
   };
+#endif
 
   for (uint32_t top = c_max; top > 0;) {
     const uint32_t m = top < (uint32_t)kBatch ? top : (uint32_t)kBatch;
