@@ -21,6 +21,11 @@
 #ifndef PS_ABLATE_ATTN
 #define PS_ABLATE_ATTN 0
 #endif
+// PS_ABLATE_DFMAP (same kind of experiment on the two-pass feature-map gradient's gather kernel):
+// 1: the walk without its LDS read-modify-writes, 2: without the token-row loads
+#ifndef PS_ABLATE_DFMAP
+#define PS_ABLATE_DFMAP 0
+#endif
 
 namespace ps {
 
@@ -1307,9 +1312,22 @@ epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ 
             if (toks) { toks &= toks - 1; ++n; }
           }
           float df[kDfTokGroup][CPL];
+#if PS_ABLATE_DFMAP == 2      // timing experiment: the walk without the token-row loads
+#pragma unroll
+          for (int q = 0; q < kDfTokGroup; ++q)
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) df[q][i] = cur.x;
+#else
 #pragma unroll
           for (int q = 0; q < kDfTokGroup; ++q)
             if (q < n) load_cpl<CPL>(rows + (size_t)tl[q] * dm.c, df[q]);
+#endif
+#if PS_ABLATE_DFMAP == 1      // timing experiment: rows loaded, no LDS read-modify-writes
+#pragma unroll
+          for (int q = 0; q < kDfTokGroup; ++q)
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) asm volatile("" :: "v"(df[q][i]));
+#else
 #pragma unroll
           for (int q = 0; q < kDfTokGroup; ++q) {
             if (q < n) {
@@ -1329,6 +1347,7 @@ epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ 
               }
             }
           }
+#endif
         }
         cur = nxt;
       }
