@@ -190,6 +190,35 @@ def ambiguity_mask(st: ForwardState, tol_alpha: float = 3e-6, tol_T: float = 3e-
     return mask.reshape(P.H, P.W)
 
 
+def explain_threshold_pixels(st: ForwardState, image, final_T, n_contrib, select, tol: float = 1e-4,
+                             tol_alpha: float = 3e-6, tol_T: float = 3e-6,
+                             tol_power: float = 1e-7) -> dict:
+    """Constructive check of the pixels `select` (normally the ambiguity mask) of a result under
+    test (`image` [3,H,W], `final_T`, `n_contrib` [H*W]): is it the oracle's walk with nothing
+    but FLAGGED decisions flipped (ps_oracle_blend_explain)?  Returns counts: selected,
+    same (explained by the unflipped walk), flipped (explained with >= 1 flipped decision),
+    unexplained (no such walk: a real error), exhausted (search budget), and the verdict map."""
+    L = lib()
+    dtype = st.dtype
+    suf = "_f32" if dtype == np.float32 else "_f64"
+    real = C.c_float if dtype == np.float32 else C.c_double
+    P = st.params
+    n = P.H * P.W
+    sel = np.ascontiguousarray(np.asarray(select).reshape(n) != 0, np.uint8)
+    img = np.ascontiguousarray(image, dtype).reshape(3, n)
+    fT = np.ascontiguousarray(final_T, dtype).reshape(n)
+    nc = np.ascontiguousarray(n_contrib, np.uint32).reshape(n)
+    verdict = np.zeros(n, np.uint8)
+    pl = st.point_list if st.num_rendered else np.zeros(1, np.uint32)
+    getattr(L, "ps_oracle_blend_explain" + suf)(
+        C.byref(P), _ptr(st.ranges), _ptr(pl), _ptr(st.xy), _ptr(st.conic_opacity), _ptr(st.rgb),
+        _ptr(st.bg), real(tol_alpha), real(tol_T), real(tol_power), real(tol), _ptr(sel), _ptr(img),
+        _ptr(fT), _ptr(nc), _ptr(verdict))
+    return dict(selected=int(sel.sum()), same=int((verdict == 1).sum()),
+                flipped=int((verdict == 2).sum()), unexplained=int((verdict == 3).sum()),
+                exhausted=int((verdict == 4).sum()), verdict=verdict.reshape(P.H, P.W))
+
+
 def blend_stats(st: ForwardState) -> tuple[int, int]:
     """((pixel, entry) pairs the reference walk evaluates, pairs that contribute)."""
     L = lib()

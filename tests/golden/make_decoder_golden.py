@@ -47,6 +47,8 @@ CAMERA_CONFIGS = {
     "c2_256_s1": (1, (256, 256), 2, 4, 1),
     "c4_256_v3": (1, (256, 256), 3, 4, 0),
     "c5_512": (1, (512, 512), 2, 4, 0),
+    # the BENCHMARKED launch of configs[1]: all 7 scenes x 4 views of the batch in one call
+    "c2_256_b7": (7, (256, 256), 2, 4, 0),
 }
 
 

@@ -148,3 +148,35 @@ def test_means2d_gradient_is_ndc_scaled_pixel_gradient():
     st = R.forward(dtype=np.float64, **sc)
     g = R.backward(st, np.ones((3, 32, 32)))
     assert np.array_equal(g["means2D"][:, :2], g["xy"]) and np.all(g["means2D"][:, 2] == 0)
+
+
+def test_explain_threshold_pixels():
+    """The constructive check of the threshold pixels (R.explain_threshold_pixels): a second
+    render whose alpha threshold is shifted INSIDE the tolerance band is the first render with
+    flagged decisions flipped -- every pixel is explained, some with flips; a corrupted pixel and
+    a wrong contributor count are not."""
+    sc = small_scene(400, (48, 48), seed=3, dtype=np.float32, opacity_hi=0.9)
+    st = R.forward(dtype=np.float32, **sc)
+    everything = np.ones((48, 48), np.uint8)
+    ex = R.explain_threshold_pixels(st, st.image, st.final_T, st.n_contrib, everything)
+    assert ex["same"] == 48 * 48 and ex["flipped"] == ex["unexplained"] == ex["exhausted"] == 0
+    # shifted thresholds (well inside a wide band): another valid walk over the same lists
+    st2 = R.forward(dtype=np.float32, alpha_min=st.params.alpha_min * 1.02,
+                    t_min=st.params.t_min * 1.02, **sc)
+    assert np.array_equal(st.point_list, st2.point_list)
+    changed = np.abs(st2.image - st.image).max(0) > 1e-6
+    assert changed.sum() > 20
+    wide = dict(tol_alpha=0.05, tol_T=0.05)
+    ex2 = R.explain_threshold_pixels(st, st2.image, st2.final_T, st2.n_contrib, everything,
+                                     tol=1e-6, **wide)
+    assert ex2["unexplained"] == ex2["exhausted"] == 0 and ex2["flipped"] >= changed.sum() * 0.9
+    # ... but not explainable inside the default (3e-6) band
+    ex3 = R.explain_threshold_pixels(st, st2.image, st2.final_T, st2.n_contrib, changed, tol=1e-6)
+    assert ex3["unexplained"] > 0.9 * changed.sum()
+    # garbage on a selected pixel, and a wrong last-contributor index, are caught
+    bad = st.image.copy()
+    bad[1, 7, 9] += 2e-3
+    nc = st.n_contrib.copy().reshape(48, 48)
+    nc[20, 20] += 1
+    ex4 = R.explain_threshold_pixels(st, bad, st.final_T, nc, everything, **wide)
+    assert ex4["unexplained"] == 2 and set(zip(*np.nonzero(ex4["verdict"] == 3))) == {(7, 9), (20, 20)}
