@@ -55,12 +55,15 @@ def parse():
                         "the rest of the network (the reference reduces ~480 MB; SURVEY.md 5)")
     p.add_argument("--bucket-mb", type=float, default=25.0, help="gradient bucket size (torch DDP default)")
     p.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
-                   help="graph: the step is replayed from two hipGraphs ((A) fwd+bwd, (B) fwd+bwd; "
+                   help="graph / auto: the step is replayed from two hipGraphs ((A) fwd+bwd, (B) fwd+bwd; "
                         "fixed-capacity tile lists, no host sync), the gradient all-reduce launched "
-                        "between them; eager: launch by launch; auto: graph on one GPU, eager on "
-                        "several (capture next to a live RCCL communicator is untested on this "
-                        "pool: the watchdog thread may touch the device during capture)")
-    p.add_argument("--cpu-views", type=int, default=16, help="views in the CPU-baseline sample")
+                        "between them -- for every N, so that a scaling curve compares like with like "
+                        "(capture runs in thread_local error mode next to a live RCCL communicator; "
+                        "if it fails the run falls back to eager launches and reports it); eager: "
+                        "launch by launch.  `paths.eager_ms_per_step` carries the eager time of the "
+                        "same step at every N either way")
+    p.add_argument("--cpu-views", type=int, default=10 ** 6,
+                   help="views in the CPU-baseline sample / parity block (default: every view of the step)")
     return p.parse_args()
 
 
@@ -112,11 +115,16 @@ def pmc_valu_busy_ms(group):
     return tot or None
 
 
-def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
+def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu, dL, grad_fn):
     """The oracle (CPU port of the same algorithm) timed on the host cores over a bounded
-    sample of the same workload: the first `n_views` views of the batch (scene-major),
-    forward + backward.  Also the parity figure: L_inf / PSNR of the GPU render against the
-    oracle render of the same views."""
+    sample of the same workload: the first `n_views` views of the batch (scene-major; default:
+    all of them), forward + backward.  Also the parity block of the line, over the SAME launch the
+    timed region runs (all scenes in one call): bins, image, final_T, n_contrib per view, the
+    constructive check of the threshold pixels, and the four gradient tensors per scene.
+
+    `gpu`: dict(images, final_T, n_contrib, counts, offsets, plist, radii) of the product's
+    forward as numpy arrays; `grad_fn(dL)` runs the product's backward for that dL/dimage and
+    returns (d_means, d_cov, d_sh, d_opacity) per scene."""
     import numpy as np
     from oracle import raster_ref as R
     from tests.cases import oracle_view_inputs
@@ -125,28 +133,71 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
     R.parallel_backward(True)
     cores = os.cpu_count() or 1
     t_total = 0.0
-    linf_all, linf_ok, mse, n_over, n_marked, n_pix = 0.0, 0.0, [], 0, 0, 0
+    linf_all, linf_ok, linf_T, mse, n_over, n_marked, n_pix = 0.0, 0.0, 0.0, [], 0, 0, 0
+    nc_mismatch = bins_mismatch = radii_mismatch = 0
+    explain = dict(same=0, flipped=0, unexplained=0, exhausted=0)
     pairs_eval = pairs_contrib = 0
     vps = tgt.near.shape[1]
+    G = gaussians.means.shape[1]
+    n_scenes = (n_views + vps - 1) // vps
+    ref = dict(means=np.zeros((n_scenes, G, 3)), cov=np.zeros((n_scenes, G, 3, 3)),
+               sh=np.zeros((n_scenes, G, 3, gaussians.harmonics.shape[-1])), op=np.zeros((n_scenes, G)))
+    row, col = np.triu_indices(3)
+    dL = dL.copy()
     for v in range(n_views):
         inp = oracle_view_inputs(gaussians, tgt, v // vps, v % vps, view_params=vps_np[v])
         t0 = time.perf_counter()
         st = R.forward(H=hw[0], W=hw[1], **inp)
-        R.backward(st, dL[v])
         t_total += time.perf_counter() - t0
+        # ---- parity of this view (not timed) ----
         ev_, co_ = R.blend_stats(st)
         pairs_eval += ev_
         pairs_contrib += co_
-        diff = np.clip(gpu_images[v], 0, 1) - np.clip(st.image, 0, 1)
-        err = np.abs(gpu_images[v] - st.image).max(0)
+        img = gpu["images"][v]
+        radii_mismatch += int((gpu["radii"][v] != st.radii).sum())
+        cnt = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
+        o0 = int(gpu["offsets"][v, 0])
+        same_bins = (np.array_equal(gpu["counts"][v], cnt)
+                     and np.array_equal(gpu["plist"][o0:o0 + st.num_rendered], st.point_list))
+        bins_mismatch += 0 if same_bins else 1
+        diff = np.clip(img, 0, 1) - np.clip(st.image, 0, 1)
+        err = np.abs(img - st.image).max(0)
         amb = R.ambiguity_mask(st) != 0     # pixels sitting on alpha = 1/255 or T = 1e-4
         linf_all = max(linf_all, float(err.max()))
         linf_ok = max(linf_ok, float(err[~amb].max()))
+        linf_T = max(linf_T, float(np.abs(gpu["final_T"][v] - st.final_T.reshape(hw))[~amb].max()))
+        nc_mismatch += int((gpu["n_contrib"][v][~amb] != st.n_contrib.reshape(hw)[~amb]).sum())
         n_over += int((err[~amb] > 1e-4).sum())
         n_marked += int(amb.sum())
         n_pix += err.size
         mse.append(float((diff ** 2).mean()))
+        ex = R.explain_threshold_pixels(st, img, gpu["final_T"][v], gpu["n_contrib"][v], amb, tol=1e-4)
+        for k in explain:
+            explain[k] += ex[k]
+        dL[v][:, amb] = 0.0
+        # ---- backward (timed) ----
+        t0 = time.perf_counter()
+        gr = R.backward(st, dL[v])
+        t_total += time.perf_counter() - t0
+        si, scale = v // vps, float(vps_np[v, 40])
+        ref["means"][si] += gr["means3D"] * scale
+        cg = np.zeros((G, 3, 3))
+        cg[:, row, col] = gr["cov6"]
+        ref["cov"][si] += cg * scale ** 2
+        ref["sh"][si] += gr["sh"].transpose(0, 2, 1)
+        ref["op"][si] += gr["opacity"]
     R.parallel_backward(False)
+    # gradients of every sampled scene whose views were all sampled
+    grads = {}
+    full_scenes = n_views // vps
+    if full_scenes:
+        got = dict(zip(("means", "cov", "sh", "op"), grad_fn(dL)))
+        for k, r in ref.items():
+            worst = 0.0
+            for si in range(full_scenes):
+                a = got[k][si].astype(np.float64)
+                worst = max(worst, float(np.abs(a - r[si]).max() / max(np.abs(r[si]).max(), 1e-30)))
+            grads[k] = worst
     m = float(np.mean(mse))
     psnr = float("inf") if m == 0 else -10.0 * float(np.log10(m))
     return dict(value=n_views / t_total, unit="views/s", cores=cores, kind="port",
@@ -155,16 +206,28 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu_images, dL):
                        f"oracle/raster_ref.c with OpenMP on {cores} threads, {t_total:.1f} s"), \
         dict(views=n_views, pairs_evaluated_by_reference=pairs_eval,
              pairs_contributing=pairs_contrib), \
-        dict(linf=linf_ok, psnr_db=psnr if psnr != float("inf") else 999.0,
+        dict(views_compared=n_views, launch="the benchmarked one: all scenes of the batch in one call",
+             linf=linf_ok, linf_final_T=linf_T, psnr_db=psnr if psnr != float("inf") else 999.0,
              pixels_compared=n_pix, pixels_over_1e_4=n_over, pixels_on_a_threshold=n_marked,
              linf_including_threshold_pixels=linf_all,
-             note="linf / pixels_over_1e_4 are over the pixels that do not sit on one of the blend's "
-                  "hard thresholds (oracle.raster_ref.ambiguity_mask: alpha within 3e-6 of 1/255, "
+             threshold_pixels_explained_without_flip=explain["same"],
+             threshold_pixels_explained_by_flipped_flagged_decisions=explain["flipped"],
+             threshold_pixels_unexplained=explain["unexplained"] + explain["exhausted"],
+             n_contrib_mismatches_off_threshold=nc_mismatch,
+             views_with_bin_mismatch=bins_mismatch, radii_mismatches=radii_mismatch,
+             gradient_scenes_compared=full_scenes,
+             gradient_err_over_max={k: float(f"{e:.3g}") for k, e in grads.items()},
+             note="linf / pixels_over_1e_4 / n_contrib are over the pixels that do not sit on one of the "
+                  "blend's hard thresholds (oracle.raster_ref.ambiguity_mask: alpha within 3e-6 of 1/255, "
                   "T(1-alpha) within 3e-6 of 1e-4); on those a last-bit difference of exp() flips a "
-                  "branch and adds or removes one minimum-alpha contribution; PSNR is over all pixels")
+                  "branch and adds or removes one minimum-alpha contribution: every such pixel is "
+                  "replayed with its flagged decisions flipped and must reproduce the product's "
+                  "colour / final_T to 1e-4 and its n_contrib exactly (threshold_pixels_*); gradients: "
+                  "worst |product - oracle| / max|oracle| per tensor over the scenes, dL/dimage = the "
+                  "step's MSE gradient zeroed on the threshold pixels; PSNR is over all pixels")
 
 
-def cpu_baseline_epipolar(et, feat_nhwc, ctx, num_samples, heads):
+def cpu_baseline_epipolar(et, feat_nhwc, ctx, num_samples, heads, view_shuffle=None):
     """Path (A) on the host: the oracle's unfused restatement (materialised kv, to_kv on every
     token -- what the reference computes) for ONE scene of the batch, forward + backward
     through torch autograd on the CPU.  Returns seconds per scene."""
@@ -175,14 +238,19 @@ def cpu_baseline_epipolar(et, feat_nhwc, ctx, num_samples, heads):
     near, far = ctx.near[:1], ctx.far[:1]
     b, v, c, h, w = f.shape
     par = {k: t.detach().cpu().requires_grad_(True) for k, t in et.state_dict().items()
-           if k.startswith(("transformer.layers", "depth_encoding")) and "self_attention" not in k}
+           if k.startswith(("transformer.layers", "depth_encoding", "view_embeddings"))
+           and "self_attention" not in k}
     t0 = time.perf_counter()
     smp = E.sample(f, ext, intr, near, far, num_samples)
     nf = (near[:, :, None, None, None], far[:, :, None, None, None])
     rd = E.relative_disparity(smp.depths.clamp(nf[0], nf[1]), nf[0], nf[1])
     enc = E.positional_encoding(rd, 10) @ par["depth_encoding.1.weight"].T \
         + par["depth_encoding.1.bias"]
-    kv = (smp.features + enc).permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
+    kv = smp.features + enc
+    if v > 2:   # epipolar_transformer.py:126-131: one embedding per other view, shuffled
+        emb = par["view_embeddings.weight"][view_shuffle.cpu()]
+        kv = kv + emb[None, None, :, None, None, :]
+    kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
     x = f.permute(0, 1, 3, 4, 2).reshape(b * v * h * w, 1, c)
     for i in range(2):
         pre = f"transformer.layers.{i}.0."
@@ -253,9 +321,13 @@ def main():
     view_shuffle = torch.randperm(vc - 1, device=dev) if vc > 2 else None
     c_ext, c_intr = ctx.extrinsics.to(dev), ctx.intrinsics.to(dev)
     c_near, c_far = ctx.near.to(dev), ctx.far.to(dev)
+    # the parameters path (A) owns: PreNorm + Attention of each epipolar layer (layers.{i}.0.*),
+    # the depth encoding, the view embeddings.  NOT layers.{i}.1.* (the feed-forward block's
+    # PreNorm) nor the image self-attention: this path never touches them, and an untouched
+    # parameter in a bucket would hold that bucket's all-reduce back until finish()
+    import re
     a_params = [p_ for n_, p_ in et.named_parameters()
-                if n_.startswith(("transformer.layers", "depth_encoding", "view_embeddings"))
-                and "self_attention" not in n_]
+                if re.match(r"transformer\.layers\.\d+\.0\.|depth_encoding\.|view_embeddings\.", n_)]
 
     def path_a():
         geo = et.epipolar_sampler.geometry(c_ext, c_intr, c_near, c_far, (hA, wA))
@@ -298,9 +370,12 @@ def main():
                 zero_grads()
                 path_a().backward()
                 path_b().backward()
+                reducer.finish()               # every rank: the hooks' buckets are reduced and re-armed
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         zero_grads()
+        reducer.remove()                       # no collective may be launched from inside a capture:
+                                               # replayed steps reduce with reducer.reduce_now()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         mode = "global" if world == 1 else "thread_local"   # other threads (RCCL watchdog) may
         with torch.cuda.graph(ga, capture_error_mode=mode):  # call into the runtime meanwhile
@@ -400,25 +475,59 @@ def main():
     n_visible = int((aux["radii"] > 0).sum().item())
     vps_np = aux["view_params"].cpu().numpy()
     gpu_images = img.detach().cpu().numpy()
+    gpu_fwd = None
+    if world == 1 and not args.no_cpu_baseline:     # the parity block compares THIS launch
+        from pixelsplat_amd.raster import state_views
+        sv_ = state_views(aux["cfg"], aux["state"], aux["layout"])
+        c_, o_, pl_ = export_bins(aux["cfg"], aux["state"], aux["layout"], aux["point_list"])
+        gpu_fwd = dict(images=gpu_images, radii=aux["radii"].cpu().numpy(),
+                       final_T=sv_["final_T"].cpu().numpy().reshape(V, *hw),
+                       n_contrib=sv_["n_contrib"].cpu().numpy().reshape(V, *hw),
+                       counts=c_.cpu().numpy(), offsets=o_.cpu().numpy(), plist=pl_.cpu().numpy())
+        del sv_, c_, o_, pl_
     del aux, counts, img
     torch.cuda.empty_cache()
 
     launch_mode = "eager"
-    if args.launch == "graph" or (args.launch == "auto" and world == 1):
+    launch_fallback = None
+    # auto = hipGraph replay for EVERY N (one launch mode along a scaling curve; a failed capture
+    # falls back to eager launches on all ranks and says so in `launch` / `launch_fallback`)
+    if args.launch in ("graph", "auto"):
         from pixelsplat_amd.raster import captured_overflow_flags
         list_cap[0] = (int(D_total * 1.25) + 4095) // 4096 * 4096
         try:
             capture_graphs()
-            step()
-            torch.cuda.synchronize()
-            captured_overflow_flags(check=True)
             launch_mode = "hipgraph"
         except Exception as err:       # capture not possible in this build: the eager schedule
             print(f"[bench] hipGraph capture failed ({type(err).__name__}: {err}); "
                   f"falling back to eager launches", file=sys.stderr)
-            graphs.clear()
-            list_cap[0] = 0
+            launch_fallback = f"{type(err).__name__}: {err}"[:300]
             torch.cuda.synchronize()
+        if world > 1:   # one mode for the whole job: any rank's failed capture sends every rank to eager
+            all_ok = -P.max_over_ranks(-1.0 if launch_mode == "hipgraph" else 0.0, world, dev) > 0.5
+            if launch_mode == "hipgraph" and not all_ok:
+                launch_mode, launch_fallback = "eager", "another rank's capture failed"
+        if launch_mode == "hipgraph":
+            try:
+                step()
+                torch.cuda.synchronize()
+                captured_overflow_flags(check=True)
+            except Exception as err:
+                if world > 1:       # the other ranks are already replaying: no consistent way back
+                    raise
+                print(f"[bench] hipGraph replay failed ({type(err).__name__}: {err}); "
+                      f"falling back to eager launches", file=sys.stderr)
+                launch_mode, launch_fallback = "eager", f"{type(err).__name__}: {err}"[:300]
+                torch.cuda.synchronize()
+        if launch_mode != "hipgraph":
+            from pixelsplat_amd.raster import release_captured_flags
+            graphs.clear()
+            release_captured_flags()
+            list_cap[0] = 0
+    if launch_mode == "eager" and args.launch != "eager":
+        reducer.reset()
+        reducer.install_hooks()
+        zero_grads()
     for _ in range(args.warmup):
         step()
     ng = lib.ps_profile_group_count()
@@ -431,9 +540,13 @@ def main():
     for _ in range(args.steps):
         step()
     P.barrier(world)
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     lib.ps_profile_enable(0)
-    elapsed = P.max_over_ranks(elapsed, world, dev)
+    elapsed = P.max_over_ranks(elapsed_local, world, dev)
+    rank_ms = P.gather_over_ranks(elapsed_local / args.steps * 1e3, world, dev)
+    exposed = reducer.exposed_ms(last=args.steps)
+    launches_before_finish = reducer.stats["launches_before_finish"]
+    eager_ms = elapsed / args.steps * 1e3
     if launch_mode == "hipgraph":
         # events cannot be read from inside a replayed graph: the same kernels are timed in an
         # eager pass of the same K steps right after the timed region (same process, same data)
@@ -441,6 +554,7 @@ def main():
         saved = dict(graphs)
         static_grads = [(t, t.grad) for t in (means, cov, sh, op, feat, *a_params)]
         graphs.clear()
+        reducer.install_hooks()         # the eager schedule reduces from the hooks
         step()
         torch.cuda.synchronize()
         lib.ps_profile_enable(1)
@@ -448,6 +562,16 @@ def main():
             step()
         torch.cuda.synchronize()
         lib.ps_profile_enable(0)
+        # the same step launched eagerly, timed like the contract's region (barrier + sync on both
+        # sides, slowest rank): the like-for-like denominator / numerator of a scaling curve
+        # whatever mode each N ended up in
+        P.barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        P.barrier(world)
+        eager_ms = P.max_over_ranks(time.perf_counter() - t0, world, dev) / args.steps * 1e3
+        reducer.remove()
         graphs.update(saved)
         for t, g_ in static_grads:      # the graphs write into these tensors
             t.grad = g_
@@ -556,12 +680,13 @@ def main():
                                          if pmc_valu_busy_ms(g_) else None)}
                 for g_ in SINGLE_KERNEL_GROUPS
                 if is_c2 and g_ in groups and groups[g_][0] > 0 and pmc_traffic(g_)[0]},
-            "launch": launch_mode,
+            "launch": launch_mode, "launch_requested": args.launch, "launch_fallback": launch_fallback,
             "library_gemm_table": ("pixelsplat_amd/gemm_tuning/gfx950_rocm7_torch2.10.csv"
                                    if tuned_gemms else None),
             "kernels_ms": {k: round(groups[k][0], 4) for k in groups},
             "kernel_launches_per_step": {k: groups[k][1] / args.steps for k in groups},
             "paths": {
+                "eager_ms_per_step": round(eager_ms, 3),
                 "raster_only_ms_per_step": round(ms_b, 3),
                 "raster_only_views_per_s": round(V / ms_b * 1e3 * world, 1),
                 "epipolar_only_ms_per_step": round(ms_a, 3),
@@ -584,6 +709,13 @@ def main():
                 "gradient_bytes_per_step": 4 * sum(p_.numel() for p_ in a_params),
                 "extra_payload_bytes_per_step": int(args.grad_payload_mb * 1e6),
                 "bucket_mb": args.bucket_mb, **{k_: v_ for k_, v_ in reducer.stats.items()},
+                # collectives of the timed steps launched BEFORE finish() (from the gradient hooks /
+                # reduce_now, i.e. under the rasterizer's backward) and what finish() still waited
+                "launches_before_finish_total": launches_before_finish,
+                "exposed_ms_per_step": (round(sum(exposed) / len(exposed), 4) if exposed else 0.0),
+                "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
+                                     "all": [round(x, 3) for x in rank_ms]},
+                **P.comm_info(world, dev),
             },
             "whole_path": {
                 # (B)'s reference-algorithm bytes over (B)'s own step time
@@ -596,7 +728,15 @@ def main():
             dL = (2.0 * (torch.from_numpy(gpu_images) - target.reshape(V, 3, *hw))
                   / gpu_images.size).numpy()
             nv = min(args.cpu_views, V)
-            cb, work, parity = cpu_baseline(g, tgt, vps_np, hw, nv, gpu_images, dL)
+
+            def product_gradients(dl_np):
+                """The product's backward of the same one-call launch for a given dL/dimage."""
+                zero_grads()
+                img_ = render_cuda(ext, intr, near, far, hw, bg, means, cov, sh, op, views_per_scene=v)
+                (img_ * torch.from_numpy(dl_np).to(dev)).sum().backward()
+                return tuple(t.grad.cpu().numpy() for t in (means, cov, sh, op))
+
+            cb, work, parity = cpu_baseline(g, tgt, vps_np, hw, nv, gpu_fwd, dL, product_gradients)
             # VALU roofline of the two blend kernels: USEFUL fp32 operations = the (pixel, entry)
             # pairs that pass the alpha test (counted by the oracle on the sampled views, scaled
             # to the step) x the operations of the reference algorithm per such pair (A.3: 21
@@ -616,7 +756,7 @@ def main():
                     "avg_kernel_ms": round(t_ms, 4),
                     "valu_issue_frac": (round(pmc_valu_busy_ms(kname) / t_ms, 3)
                                         if pmc_valu_busy_ms(kname) else None)}
-            t_a = cpu_baseline_epipolar(et, feat, ctx, n_samp, heads)       # one scene
+            t_a = cpu_baseline_epipolar(et, feat, ctx, n_samp, heads, view_shuffle)   # one scene
             t_step = b * t_a + V / cb["value"]
             cb["raster_only_views_per_s"] = round(cb["value"], 3)
             cb["epipolar_s_per_scene"] = round(t_a, 2)

@@ -261,17 +261,27 @@ class FeatureGradBatch:
         total = None
         boxes = torch.empty((max(flags.numel(), lib.ps_epipolar_ray_box_words(C.byref(desc))),),
                             dtype=torch.int32, device=fmap.device)
+        # two-pass scheme: token gradients once (d(kv) of the reference: b v (v-1) h w s c floats of
+        # caller-owned scratch, 0.94 GB at BASELINE configs[1], 1.6 GB at configs[3] -- it sits in
+        # the backward-time peak, INTEGRATION.md "memory"), then the tile gather.  One scratch for
+        # all launch groups; if it cannot be allocated (or PS_DFMAP_SCRATCH_MAX_MB says it is too
+        # much) the single-pass kernel -- no scratch, ~15 % slower -- takes over.
+        scratch = None
+        if TWO_PASS_FEATURE_GRAD:
+            need = lib.ps_epipolar_token_grad_floats(C.byref(desc))
+            limit_mb = float(_os.environ.get("PS_DFMAP_SCRATCH_MAX_MB", "0") or 0)
+            if not (limit_mb > 0 and need * 4 > limit_mb * (1 << 20)):
+                try:
+                    scratch = torch.empty((need,), dtype=torch.float32, device=fmap.device)
+                except torch.OutOfMemoryError:
+                    scratch = None
         while self.pending:
             group, self.pending = (self.pending[:self.MAX_PER_LAUNCH],
                                    self.pending[self.MAX_PER_LAUNCH:])
             n = len(group)
             arr = lambda k, off=0: (C.c_void_p * n)(*[t[k].data_ptr() + 4 * off for t in group])
             dfmap = torch.empty_like(fmap)
-            if TWO_PASS_FEATURE_GRAD:
-                # token gradients once (d(kv) of the reference, caller-owned scratch), then the
-                # tile gather: a ray's coefficient rows are not reloaded per tile
-                scratch = torch.empty((lib.ps_epipolar_token_grad_floats(C.byref(desc)),),
-                                      dtype=torch.float32, device=fmap.device)
+            if scratch is not None:
                 _lib.check(lib.ps_epipolar_feature_grad_two_pass(
                     C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
                     _p(dfmap), _p(boxes), _p(scratch), _stream()),

@@ -71,6 +71,40 @@ def max_over_ranks(value: float, world: int, device: torch.device | str = "cpu")
     return float(t.item())
 
 
+def gather_over_ranks(value: float, world: int, device: torch.device | str = "cpu") -> list[float]:
+    """Every rank's value, in rank order (on every rank)."""
+    if world <= 1:
+        return [float(value)]
+    import torch.distributed as dist
+
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def comm_info(world: int, device: torch.device | str = "cpu") -> dict:
+    """What the communicator actually is, for the bench line: backend, the number of ranks the
+    collective library itself spans (checked by all-reducing a one per rank through it), the
+    RCCL version torch was built against and the NCCL_* / RCCL_* knobs of the environment."""
+    info = dict(rccl_nranks=1 if world <= 1 else None, rccl_version=None, env={})
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:       # CPU-only build / no RCCL: stays None
+        pass
+    info["env"] = {k: v for k, v in os.environ.items()
+                   if k.startswith(("NCCL_", "RCCL_")) or k == "HSA_ENABLE_IPC_MODE_LEGACY"}
+    if world > 1:
+        import torch.distributed as dist
+
+        one = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        info["rccl_nranks"] = int(round(float(one.item())))
+        info["devices_visible"] = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return info
+
+
 def rank_seed(base: int, rank: int) -> int:
     """Distinct synthetic batches per rank (weak scaling: per-GPU work fixed)."""
     return base + rank
@@ -133,53 +167,108 @@ class GradientReducer:
     """
 
     def __init__(self, params, world: int, bucket_bytes: int = 25 << 20, average: bool = True,
-                 extra_payload_bytes: int = 0):
+                 extra_payload_bytes: int = 0, broadcast_parameters: bool = False,
+                 device: torch.device | str | None = None, rebucket_after_first_step: bool = True):
+        """`broadcast_parameters`: copy rank 0's parameter values to every rank first (torch DDP
+        does; needed when ranks seed before building the model).  `device`: where the synthetic
+        payload lives when there are no parameters.  `rebucket_after_first_step`: after the first
+        `finish()` the parameters that received no gradient in that step move to buckets of their
+        own at the end, so that the buckets of the USED parameters complete -- and launch -- from
+        the hooks, under the rest of the backward, instead of waiting for `finish()` (DDP rebuilds
+        its buckets after the first iteration for the same reason)."""
         self.world = world
         self.average = average
+        self.bucket_bytes = bucket_bytes
         self.params = [p for p in params if p.requires_grad]
         self.buckets: list[dict] = []
         self._where: dict[int, tuple[int, int]] = {}
         self._works: list = []
         self._hooks = []
-        self.stats = dict(buckets=0, bytes_per_step=0, launches=0, steps=0)
-        if world <= 1 or not self.params:
+        self._next = 0                    # next bucket to launch (index order)
+        self._given: set[int] = set()     # parameters whose .grad the reducer supplied (unused on this rank)
+        self._exposed = []                # (start, end) event pairs / seconds around finish()'s wait
+        self._rebucket = rebucket_after_first_step
+        self.extra = None
+        self.extra_chunk = max(1, bucket_bytes // 4)
+        self.stats = dict(buckets=0, bytes_per_step=0, launches=0, steps=0, launches_before_finish=0,
+                          rebucketed=False)
+        if world <= 1:
             return
-        cur, cur_n = [], 0
+        if device is None:
+            device = self.params[0].device if self.params else (
+                torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                else torch.device("cpu"))
+        if extra_payload_bytes > 0:
+            self.extra = torch.zeros(extra_payload_bytes // 4, dtype=torch.float32, device=device)
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("GradientReducer: fp32 parameters only (the path is fp32)")
+        if broadcast_parameters and self.params:
+            import torch.distributed as dist
+
+            with torch.no_grad():
+                for p in self.params:
+                    dist.broadcast(p, src=0)
+        self._build_buckets([list(reversed(self.params))])
+        self.install_hooks()
+
+    # ---- buckets -----------------------------------------------------------------------
+    def _build_buckets(self, ordered_lists) -> None:
+        """Flat buffers over the given parameter lists (a bucket never spans two lists); existing
+        bucket contents and `.grad` aliases move to the new views."""
+        old = {id(p): v for b in self.buckets for p, v in zip(b["params"], b["views"])}
         groups = []
-        for p in reversed(self.params):
-            n = p.numel()
-            if cur and (cur_n + n) * 4 > bucket_bytes:
+        for plist in ordered_lists:
+            cur, cur_n = [], 0
+            for p in plist:
+                n = p.numel()
+                if cur and (cur_n + n) * 4 > self.bucket_bytes:
+                    groups.append(cur)
+                    cur, cur_n = [], 0
+                cur.append(p)
+                cur_n += n
+            if cur:
                 groups.append(cur)
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += n
-        if cur:
-            groups.append(cur)
+        self.buckets, self._where = [], {}
         for bi, grp in enumerate(groups):
             total = sum(p.numel() for p in grp)
             flat = torch.zeros(total, dtype=torch.float32, device=grp[0].device)
-            off = 0
-            views = []
+            off, views = 0, []
             for p in grp:
-                if p.dtype != torch.float32:
-                    raise TypeError("GradientReducer: fp32 parameters only (the path is fp32)")
                 self._where[id(p)] = (bi, len(views))
-                views.append(flat[off:off + p.numel()].view_as(p))
+                view = flat[off:off + p.numel()].view_as(p)
+                prev = old.get(id(p))
+                if prev is not None:
+                    view.copy_(prev)
+                    if p.grad is not None and p.grad.data_ptr() == prev.data_ptr():
+                        p.grad = view
+                views.append(view)
                 off += p.numel()
             self.buckets.append(dict(flat=flat, params=grp, views=views, ready=[False] * len(grp),
                                      pending=len(grp), launched=False))
-        self.extra = None
-        if extra_payload_bytes > 0:
-            self.extra = torch.zeros(extra_payload_bytes // 4, dtype=torch.float32,
-                                     device=self.params[0].device)
-            self.extra_chunk = max(1, bucket_bytes // 4)
         self.stats["buckets"] = len(self.buckets)
         self.stats["bytes_per_step"] = 4 * sum(b["flat"].numel() for b in self.buckets) + \
             (0 if self.extra is None else 4 * self.extra.numel())
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _launch(self, b: dict) -> None:
+    def install_hooks(self) -> None:
+        if self.world > 1 and not self._hooks:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def reset(self) -> None:
+        """Forget a half-finished step (e.g. after a failed hipGraph capture): waits for what was
+        launched, re-arms every bucket."""
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        for b in self.buckets:
+            b.pop("copy_back", None)
+            b["ready"] = [False] * len(b["params"])
+            b["pending"] = len(b["params"])
+            b["launched"] = False
+        self._next = 0
+
+    def _launch(self, b: dict, in_finish: bool = False) -> None:
         import torch.distributed as dist
 
         if self.average:
@@ -187,6 +276,8 @@ class GradientReducer:
         self._works.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
         b["launched"] = True
         self.stats["launches"] += 1
+        if not in_finish:
+            self.stats["launches_before_finish"] += 1
 
     def _on_grad(self, p: torch.Tensor) -> None:
         bi, slot = self._where[id(p)]
@@ -196,32 +287,43 @@ class GradientReducer:
                                "(two backward passes through the same parameter in one step: "
                                "call finish() between them or accumulate before reducing)")
         view = b["views"][slot]
+        self._given.discard(id(p))
         if p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)
             p.grad = view
         if not b["ready"][slot]:
             b["ready"][slot] = True
             b["pending"] -= 1
-        if b["pending"] == 0:
-            self._launch(b)
+        # buckets launch in INDEX order only (as torch DDP does): collectives are matched by
+        # issue order, and which bucket completes first may differ between ranks (a parameter
+        # unused on one rank holds its bucket back there until finish())
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def reduce_now(self) -> None:
         """Hook-free variant for steps replayed from hipGraphs (the gradients are static tensors
         written by the graph, no accumulate hook fires): copies every gradient into its bucket
         and launches the buckets' all-reduces asynchronously.  `finish()` waits and copies the
-        means back into the gradient tensors.  Parameters without a gradient count as zero."""
+        means back into the gradient tensors.  Parameters without a gradient of their own -- None,
+        or a tensor a previous `finish()` supplied because the parameter was unused on this rank
+        -- count as zero."""
         if self.world <= 1 or not self.params:
             return
         for b in self.buckets:
+            if b["launched"]:
+                raise RuntimeError("GradientReducer.reduce_now(): the previous step was not finished")
             for slot, (p, view) in enumerate(zip(b["params"], b["views"])):
-                if p.grad is None:
+                own = p.grad is not None and id(p) not in self._given
+                if not own:
                     view.zero_()
                 elif p.grad.data_ptr() != view.data_ptr():
                     view.copy_(p.grad)
-                b["ready"][slot] = p.grad is not None
+                b["ready"][slot] = own
             b["pending"] = 0
             b["copy_back"] = True
             self._launch(b)
+        self._next = len(self.buckets)
 
     def launch_extra_payload(self) -> None:
         """All-reduce of the synthetic payload (the rest of the network's gradients), in
@@ -234,34 +336,78 @@ class GradientReducer:
             self._works.append(dist.all_reduce(self.extra[off:off + self.extra_chunk],
                                                op=dist.ReduceOp.SUM, async_op=True))
             self.stats["launches"] += 1
+            self.stats["launches_before_finish"] += 1
 
     def finish(self) -> None:
         """End of the step: reduce what is still incomplete (unused parameters count as zero),
         wait for every collective, re-arm."""
-        if self.world <= 1 or not self.params:
+        if self.world <= 1:
             return
         for b in self.buckets:
             if not b["launched"]:
                 for slot, ok in enumerate(b["ready"]):
                     if not ok:
                         b["views"][slot].zero_()
-                self._launch(b)
+                self._launch(b, in_finish=True)
+        # exposed communication: how long the compute stream (or the host, without a GPU) stands
+        # in the waits below, i.e. what the rest of the step did not hide
+        on_gpu = bool(self._works) and torch.cuda.is_available() and (
+            (self.buckets and self.buckets[0]["flat"].is_cuda) or
+            (self.extra is not None and self.extra.is_cuda))
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        else:
+            import time
+            t0 = time.perf_counter()
         for w in self._works:
             w.wait()
+        if on_gpu:
+            e1.record()
+            self._exposed.append((e0, e1))
+        elif self._works:
+            self._exposed.append(time.perf_counter() - t0)
         self._works.clear()
         for b in self.buckets:
             if b.pop("copy_back", False):      # reduce_now(): static gradient tensors keep their
-                for p, view in zip(b["params"], b["views"]):   # storage, the mean is copied back
-                    if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                for p, view, ok in zip(b["params"], b["views"], b["ready"]):   # storage: copy back
+                    if ok and p.grad.data_ptr() != view.data_ptr():
                         p.grad.copy_(view)
             # a parameter unused on THIS rank still receives the other ranks' mean gradient
             for p, view, ok in zip(b["params"], b["views"], b["ready"]):
                 if not ok:
                     p.grad = view
+                    self._given.add(id(p))
+        if self._rebucket and self.stats["steps"] == 0 and self.buckets:
+            # one-time: the parameters NO rank touched in this step get their own trailing
+            # buckets (the decision is all-reduced: every rank must end up with the same layout)
+            import torch.distributed as dist
+
+            flags = torch.tensor([float(ok) for b in self.buckets for ok in b["ready"]],
+                                 dtype=torch.float32, device=self.buckets[0]["flat"].device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            flags = iter(flags.tolist())
+            used, unused = [], []
+            for b in self.buckets:
+                for p in b["params"]:
+                    (used if next(flags) > 0 else unused).append(p)
+            if used and unused:
+                self._build_buckets([used, unused])
+                self.stats["rebucketed"] = True
+        for b in self.buckets:
             b["ready"] = [False] * len(b["params"])
             b["pending"] = len(b["params"])
             b["launched"] = False
+        self._next = 0
         self.stats["steps"] += 1
+
+    def exposed_ms(self, last: int | None = None) -> list[float]:
+        """Per finished step: milliseconds the compute stream (GPU) or the host (CPU backend)
+        stood waiting for the collectives in `finish()`.  Synchronises the device."""
+        if torch.cuda.is_available() and any(not isinstance(e, float) for e in self._exposed):
+            torch.cuda.synchronize()
+        vals = [e * 1e3 if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in self._exposed]
+        return vals if last is None else vals[-last:]
 
     def remove(self) -> None:
         for h in self._hooks:

@@ -193,24 +193,41 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
 
 
 _SIDE_STREAMS: dict = {}
-_PINNED_FLAGS: list = []      # pinned [2] int32 buffers of the fixed-capacity mode, recycled
-_PINNED_NEXT = [0]
+_CAPTURE_FREE: list = []      # pinned buffers reserved for forwards recorded into a hipGraph
 _CAPTURED_FLAGS: list = []    # (flag, capacity) of forwards recorded into a hipGraph
+_CAPTURE_RESERVE = 32
+
+
+def reserve_capture_flags(n: int = _CAPTURE_RESERVE) -> None:
+    """Pinned 8-byte landing buffers for fixed-capacity forwards that will be recorded into
+    hipGraphs: pinned memory cannot be allocated while a stream is being captured, so they are
+    set aside beforehand (the first eager fixed-capacity call reserves 32).  Every recorded
+    forward gets a buffer of its OWN for the lifetime of its graph -- two forwards of one graph,
+    or of two live graphs, never share a landing buffer."""
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("reserve_capture_flags() must be called outside a capture")
+    while len(_CAPTURE_FREE) < n:
+        _CAPTURE_FREE.append(torch.empty(2, dtype=torch.int32, pin_memory=True))
+
+
+def release_captured_flags() -> None:
+    """Forget the forwards recorded so far (their graphs are gone: re-capture, failed capture);
+    their landing buffers return to the reserve."""
+    while _CAPTURED_FLAGS:
+        _CAPTURE_FREE.append(_CAPTURED_FLAGS.pop()[0])
 
 
 def _pinned_flag() -> Tensor:
-    """A pinned 8-byte landing buffer for (D, overflow).  Pinned allocations are not allowed while
-    a stream is being captured, so the buffers of the eager warm-up steps are kept and handed out
-    round-robin (one per rasterize call of a step)."""
+    """A pinned 8-byte landing buffer for (D, overflow)."""
     if torch.cuda.is_current_stream_capturing():
-        if not _PINNED_FLAGS:
-            raise RuntimeError("pixelsplat_amd.rasterize under hipGraph capture: run one eager "
-                               "(warm-up) step with the same list_capacity first")
-        _PINNED_NEXT[0] = (_PINNED_NEXT[0] + 1) % len(_PINNED_FLAGS)
-        return _PINNED_FLAGS[_PINNED_NEXT[0]]
-    if len(_PINNED_FLAGS) < 16:
-        _PINNED_FLAGS.append(torch.empty(2, dtype=torch.int32, pin_memory=True))
-        return _PINNED_FLAGS[-1]
+        if not _CAPTURE_FREE:
+            raise RuntimeError(
+                "pixelsplat_amd.rasterize under hipGraph capture: no landing buffer left for the "
+                "overflow flag -- run one eager (warm-up) step with the same list_capacity first, "
+                "or raster.reserve_capture_flags(n) for more than 32 recorded forwards, and "
+                "raster.release_captured_flags() when graphs are dropped")
+        return _CAPTURE_FREE.pop()
+    reserve_capture_flags()
     return torch.empty(2, dtype=torch.int32, pin_memory=True)   # caching host allocator
 
 

@@ -79,6 +79,26 @@ def test_rasterizer_step_replayed_from_a_graph_equals_eager(gpu_device):
     with pytest.raises(RuntimeError, match="list_capacity"):
         captured_overflow_flags(check=True)
 
+    # two forwards recorded into ONE graph never share a landing buffer: the fitting
+    # call's flag is not overwritten by the overflowing one's
+    from pixelsplat_amd.raster import release_captured_flags
+    release_captured_flags()
+    assert captured_overflow_flags(check=False) == []
+    for t in leaves:
+        t.grad = None
+    both = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(both):
+        step(cap)
+        for t in leaves:
+            t.grad = None
+        step(2048)
+    both.replay()
+    torch.cuda.synchronize()
+    fl = captured_overflow_flags(check=False)
+    assert len(fl) == 2 and fl[0][2] == cap and fl[1][2] == 2048
+    assert not fl[0][1] and fl[1][1] and fl[0][0] == flags[-1][0]
+    release_captured_flags()
+
 
 def test_epipolar_layers_replayed_from_a_graph_equal_eager_and_are_deterministic(gpu_device):
     """Two fused cross-attention layers sharing a FeatureGradBatch (two-pass feature-map
