@@ -81,31 +81,58 @@ SINGLE_KERNEL_GROUPS = {
 PMC_TAG = None    # "c2" | "c4" | "c5": which committed counter summaries match this run
 
 
-def _pmc_file(kind):
+# translation unit behind each single-kernel group: a committed counter summary is paired with a
+# live kernel time only if that unit has the same hash in the summary and in the loaded library
+GROUP_UNIT = {"tiles_backward": "raster_tiles", "tiles_forward": "raster_tiles",
+              "epipolar_attention_forward": "epipolar_attention",
+              "epipolar_attention_backward": "epipolar_attention",
+              "epipolar_feature_grad": "epipolar_attention",
+              "gaussian_adapter_backward": "gaussian_adapter",
+              "depth_sampler_forward": "depth_sampler", "depth_sampler_backward": "depth_sampler"}
+_LIB_HASHES = {}
+
+
+def _unit_hashes(text):
+    return dict(tok.split(":", 1) for tok in (text or "").split() if ":" in tok)
+
+
+def _pmc_file(kind, group):
+    """Newest committed `profiles/*_<tag>_pmc_<kind>.json` whose build stamp carries the SAME hash
+    for the group's translation unit as the loaded library (ps_build_info); None (-> null in the
+    line) when no summary matches: stale counters are never paired with new times."""
     import glob
     if PMC_TAG is None:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{PMC_TAG}_pmc_{kind}.json")))
-    return files[-1] if files else None
+    unit = GROUP_UNIT.get(group)
+    want = _LIB_HASHES.get(unit)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{PMC_TAG}_pmc_{kind}.json")),
+                       key=os.path.getmtime, reverse=True):
+        with open(path) as f:
+            stamp = json.load(f).get("build")
+        if want is not None and _unit_hashes(stamp).get(unit) == want:
+            return path
+    return None
 
 
 def pmc_traffic(group):
     """HBM-side bytes per launch of the kernel(s) behind a profile group, from the committed
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of the SAME workload (tools/pmc_summary.py;
-    counters cannot be read from inside the process).  None when there is no summary."""
-    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("traffic")
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of the SAME workload AND the same code
+    (tools/pmc_summary.py; counters cannot be read from inside the process).  None otherwise."""
+    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("traffic", group)
     if keys is None or path is None:
         return None, None
     with open(path) as f:
-        kernels = json.load(f)["kernels"]
-    total = sum(float(v["bytes"]) for name, v in kernels.items() if any(k in name for k in keys))
-    return (total, os.path.basename(path)) if total else (None, None)
+        doc = json.load(f)
+    total = sum(float(v["bytes"]) for name, v in doc["kernels"].items() if any(k in name for k in keys))
+    src = f"{os.path.basename(path)} (git {str(doc.get('git'))[:12]}, {GROUP_UNIT.get(group)}:" \
+          f"{_LIB_HASHES.get(GROUP_UNIT.get(group))} = loaded library)"
+    return (total, src) if total else (None, None)
 
 
 def pmc_valu_busy_ms(group):
     """VALU-busy time per launch (SQ_ACTIVE_INST_VALU quad-cycles x 4 / 1024 SIMDs at 2.4 GHz) of
     the kernel(s) behind a profile group, from the committed PMC summary (tools/pmc_sq_summary.py)."""
-    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("sq")
+    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("sq", group)
     if keys is None or path is None:
         return None
     with open(path) as f:
@@ -283,6 +310,8 @@ def main():
     from pixelsplat_amd.synthetic import make_workload
 
     lib = _lib.load()  # raises if the HIP library is missing: no fallback
+    build_info = lib.ps_build_info().decode()
+    _LIB_HASHES.update(_unit_hashes(build_info.split("|", 1)[-1]))
     # library GEMMs: committed TunableOp table, look-up only (pixelsplat_amd/gemm_tuning)
     tuned_gemms = (not os.environ.get("PIXELSPLAT_NO_TUNED_GEMMS")) and gemm_tuning.enable()
     hw = (args.size, args.size)
@@ -657,6 +686,10 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_note": (None if traffic is not None else
+                                 "no committed counter summary was taken on this build of the kernel "
+                                 "(profiles/*_pmc_traffic.json `build` vs ps_build_info): null rather "
+                                 "than stale; tools/profile_bench.sh re-collects it"),
                 "avg_kernel_ms": round(dom_ms, 4),
                 "kernel_timing": ("HIP events around the kernel's launches over the timed steps"
                                   if launch_mode == "eager" else
@@ -680,6 +713,7 @@ def main():
                                          if pmc_valu_busy_ms(g_) else None)}
                 for g_ in SINGLE_KERNEL_GROUPS
                 if is_c2 and g_ in groups and groups[g_][0] > 0 and pmc_traffic(g_)[0]},
+            "build": build_info,
             "launch": launch_mode, "launch_requested": args.launch, "launch_fallback": launch_fallback,
             "library_gemm_table": ("pixelsplat_amd/gemm_tuning/gfx950_rocm7_torch2.10.csv"
                                    if tuned_gemms else None),

@@ -491,13 +491,21 @@ int ps_gemm_tn_colsum_f32(int32_t m, int32_t n, int32_t k, const float* a, int32
  * library).  When enabled every kernel group the library launches is bracketed by hipEvents
  * on the caller's stream; ps_profile_collect synchronises those events, ADDS the elapsed
  * milliseconds / launch counts per group into the caller's arrays (length
- * ps_profile_group_count()) and clears the pending list. */
+ * ps_profile_group_count()) and clears the pending list.
+ * `on` is a bit set: 1 = the hipEvent timing above; 2 = a named roctx range "ps:<group>" around
+ * every group on the calling thread (the tracing hooks of SURVEY.md 5: the reference has none of
+ * its own, Lightning's profiler plays that role), visible to `rocprofv3 --marker-trace`; PS_ROCTX=1
+ * in the environment turns the ranges on without a call.  The marker library is looked up with
+ * dlopen at first use; ps_roctx_available() tells whether one was found. */
 int ps_profile_enable(int on);
+int ps_roctx_available(void);
 int ps_profile_group_count(void);
 const char* ps_profile_group_name(int group);
 int ps_profile_collect(double* total_ms, int64_t* launches);
 
 const char* ps_status_string(int status);
+/* "pixelsplat_hip gfx950 <date> <time> | <file>:<hash> ..." -- one hash per translation unit over
+ * its source, the shared headers and the compile flags (pixelsplat_amd/build.py). */
 const char* ps_build_info(void);
 
 #ifdef __cplusplus

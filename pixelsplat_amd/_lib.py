@@ -70,7 +70,7 @@ EXPORTS = [
     "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
     "ps_raster_forward_render", "ps_raster_forward_colors", "ps_raster_forward_bins", "ps_raster_forward_tiles", "ps_raster_backward", "ps_raster_backward_prepare",
     "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
-    "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info",
+    "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info", "ps_roctx_available",
     "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_gemm_tn_colsum_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_epipolar_token_grad_floats", "ps_epipolar_ray_box_words", "ps_epipolar_feature_grad_two_pass", "ps_gaussian_adapter_views",
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
     "ps_gaussian_head_forward", "ps_gaussian_head_backward",

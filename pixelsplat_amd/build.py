@@ -40,18 +40,44 @@ def _deps(src: str) -> list[str]:
     return [src] + hdrs + [os.path.abspath(__file__)]
 
 
+def unit_hashes(units, extra_flags=()) -> str:
+    """"<file>:<hash12> ..." -- per translation unit, sha256 over its source, every shared header
+    and its compile flags.  Baked into the library (ps_build_info) and recorded with every counter
+    summary under profiles/, so that bench.py never pairs a kernel's live time with counters taken
+    on different code."""
+    import hashlib
+    shared = hashlib.sha256()
+    for h in sorted(f for f in os.listdir(CSRC) if f.endswith(".h")):
+        shared.update(open(os.path.join(CSRC, h), "rb").read())
+    shared.update(open(os.path.join(ROOT, "include", "pixelsplat_hip.h"), "rb").read())
+    out = []
+    for name, flags in units:
+        h = hashlib.sha256(shared.digest())
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+        h.update(" ".join([*COMMON[:4], *flags, *extra_flags]).encode())
+        out.append(f"{name[:-4]}:{h.hexdigest()[:12]}")
+    return " ".join(out)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     extra = [(f, []) for f in sorted(os.listdir(CSRC))
              if f.endswith(".hip") and f not in {s for s, _ in SOURCES}]
     objs = []
     rebuilt = False
     procs = []
-    for name, flags in SOURCES + extra:
+    units = SOURCES + extra
+    hashes = unit_hashes([u for u in units if u[0] != "raster_api.hip"])
+    stamp = os.path.join(CSRC, ".build_hashes")
+    hashes_changed = (not os.path.exists(stamp)) or open(stamp).read() != hashes
+    for name, flags in units:
         src = os.path.join(CSRC, name)
         obj = os.path.join(CSRC, name.replace(".hip", ".o"))
         objs.append(obj)
         stale = force or not os.path.exists(obj) or any(
             os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
+        if name == "raster_api.hip":      # carries every unit's hash (ps_build_info)
+            stale = stale or hashes_changed
+            flags = [*flags, f'-DPS_BUILD_HASHES="{hashes}"']
         if stale:
             cmd = [_hipcc(), *COMMON, *flags, "-c", src, "-o", obj]
             if verbose:
@@ -66,10 +92,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose and out.strip():
             print(out)
     if rebuilt or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(hashes)
     return LIB
 
 

@@ -3,6 +3,8 @@
 #include "raster_common.h"
 
 #include <atomic>
+#include <cstdlib>
+#include <dlfcn.h>
 #include <mutex>
 #include <vector>
 
@@ -21,19 +23,55 @@ const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bi
                                     "gemm_tn_splitk", "gaussian_adapter_forward",
                                     "gaussian_adapter_backward", "depth_sampler_forward",
                                     "depth_sampler_backward", "image_losses"};
-std::atomic<int> g_profile_on{0};
+std::atomic<int> g_profile_on{0};     // bit 0: HIP events per group, bit 1: roctx ranges per group
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
 std::vector<Pending> g_pending;
 
+// roctx ranges (the tracing row of SURVEY.md 5): every profile group is a named range
+// "ps:<group>" on the calling thread, visible to `rocprofv3 --marker-trace` next to the kernel
+// trace.  The marker library is looked up at run time (rocprofiler-sdk's roctx, else roctracer's):
+// no link-time dependency, a no-op when neither is there.  On with ps_profile_enable(2|...) or
+// PS_ROCTX=1 in the environment.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool env_on = false;
+  Roctx() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1",
+                             "libroctx64.so", "libroctx64.so.4"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) break;
+        push = nullptr; pop = nullptr;
+      }
+    }
+    const char* e = getenv("PS_ROCTX");
+    env_on = e && e[0] && e[0] != '0';
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+const char* kRangeNames[] = {"ps:preprocess_forward", "ps:depth_sort", "ps:tile_bins", "ps:tiles_forward",
+                             "ps:tiles_backward", "ps:preprocess_backward", "ps:memset",
+                             "ps:epipolar_geometry", "ps:epipolar_attention_forward",
+                             "ps:epipolar_attention_backward", "ps:epipolar_feature_grad",
+                             "ps:gemm_tn_splitk", "ps:gaussian_adapter_forward",
+                             "ps:gaussian_adapter_backward", "ps:depth_sampler_forward",
+                             "ps:depth_sampler_backward", "ps:image_losses"};
+static_assert(sizeof(kRangeNames) / sizeof(kRangeNames[0]) == G_COUNT, "one range name per group");
+
 struct Scope {
-  hipEvent_t a = nullptr, b = nullptr; int group; hipStream_t st; bool on;
-  Scope(int g, hipStream_t s) : group(g), st(s), on(g_profile_on.load() != 0) {
+  hipEvent_t a = nullptr, b = nullptr; int group; hipStream_t st; bool on; bool range = false;
+  Scope(int g, hipStream_t s) : group(g), st(s), on((g_profile_on.load() & 1) != 0) {
+    Roctx& rx = roctx();
+    if (rx.push && (rx.env_on || (g_profile_on.load() & 2))) { rx.push(kRangeNames[g]); range = true; }
     if (!on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
     hipEventRecord(a, st);
   }
   ~Scope() {
+    if (range) roctx().pop();
     if (!on) return;
     hipEventRecord(b, st);
     std::lock_guard<std::mutex> lk(g_profile_mu);
@@ -709,7 +747,8 @@ int ps_raster_check(const PsRasterDesc* d, const void* state, size_t state_bytes
   return host[1] ? PS_ERR_CAPACITY : PS_OK;
 }
 
-int ps_profile_enable(int on) { g_profile_on.store(on ? 1 : 0); return PS_OK; }
+int ps_profile_enable(int on) { g_profile_on.store(on & 3); return PS_OK; }
+int ps_roctx_available(void) { return roctx().push != nullptr; }
 int ps_profile_group_count(void) { return G_COUNT; }
 const char* ps_profile_group_name(int g) { return (g >= 0 && g < G_COUNT) ? kGroupNames[g] : ""; }
 int ps_profile_collect(double* total_ms, int64_t* launches) {
@@ -741,6 +780,13 @@ const char* ps_status_string(int status) {
   }
 }
 
-const char* ps_build_info(void) { return "pixelsplat_hip gfx950 " __DATE__ " " __TIME__; }
+// PS_BUILD_HASHES: "<file>:<hash12> ..." of every translation unit (source + headers + flags), put
+// there by pixelsplat_amd/build.py / tools/build_variant.sh.  Counter summaries under profiles/ carry
+// the same string; bench.py pairs a live kernel time with committed counters only when the
+// kernel's translation unit has the same hash in both.
+#ifndef PS_BUILD_HASHES
+#define PS_BUILD_HASHES "unhashed"
+#endif
+const char* ps_build_info(void) { return "pixelsplat_hip gfx950 " __DATE__ " " __TIME__ " | " PS_BUILD_HASHES; }
 
 }  // extern "C"

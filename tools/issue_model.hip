@@ -1,0 +1,170 @@
+// Issue-cost table of the instruction classes the blend kernels are made of, on gfx950, at the
+// occupancy those kernels run at (4 waves per SIMD; also 1, 2, 8): every SIMD of the chip loaded,
+// 8 independent chains per wave, wall clock (hipEvents) AND the shader clock the kernel saw
+// (s_memtime at both ends of wave 0), so that cycles per instruction do not depend on the
+// nominal 2.4 GHz.  The last rows are the forward and backward per-quadrant blocks of
+// raster_tiles.hip restated instruction for instruction (dependent chain, as in the kernel).
+//   hipcc --offload-arch=gfx950 -O3 tools/issue_model.hip -o tools/issue_model && tools/issue_model
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int OP>
+__global__ void __launch_bounds__(256) k(float* out, uint64_t* ticks, int iters) {
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = 1.0f + 0.001f * (threadIdx.x + i);
+  float c = 0.999f + 1e-6f * threadIdx.x, e = 0.5f + 1e-6f * threadIdx.x;
+  asm volatile("s_mov_b32 vcc_lo, 0x55555555\n s_mov_b32 vcc_hi, 0x55555555\n s_mov_b32 s10, 0x33333333\n s_mov_b32 s11, 0x33333333" ::: "vcc", "s10", "s11");
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        double& d = *(double*)&v[2 * i];
+        if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c), "v"(e));
+        if (OP == 1) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+        if (OP == 2) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(v[i]) : "v"(c), "v"(e));
+        if (OP == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d) : "v"(*(double*)&v[(2 * i + 2) & 14]));
+        if (OP == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d) : "v"(*(double*)&v[(2 * i + 2) & 14]));
+        if (OP == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d) : "v"(*(double*)&v[(2 * i + 2) & 14]));
+        if (OP == 6) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(v[i]));
+        if (OP == 7) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(v[i]));
+        if (OP == 8) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(c));
+        if (OP == 9) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(v[i]) : "v"(c));
+        if (OP == 10) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(v[i]), "v"(c) : "vcc");
+        if (OP == 11) asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %1" :: "v"(v[i]), "v"(c) : "s10", "s11");
+        if (OP == 12) asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+        if (OP == 13) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v[i]));
+        if (OP == 14) asm volatile("v_permlane32_swap_b32_e32 %0, %1" : "+v"(v[i]), "+v"(v[8 + i]));
+        if (OP == 15) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c), "v"(e));
+        if (OP == 16) asm volatile("v_sub_f32_e32 %0, 1.0, %0" : "+v"(v[i]));
+        if (OP == 17) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(v[i]) : "v"(c));
+        if (OP == 18) asm volatile("v_cndmask_b32_e64 %0, -|%0|, %1, s[10:11]" : "+v"(v[i]) : "v"(c));
+        if (OP == 19) asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n v_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(v[i]) : "v"(v[8 + i]), "v"(c) : "vcc");
+        if (OP == 20) asm volatile("v_fmac_f32_e32 %0, %1, %2\n v_mul_f32_e32 %3, %3, %1" : "+v"(v[i]), "+v"(c), "+v"(e), "+v"(v[8 + i]));
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s + c + e;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+// the forward per-quadrant block (raster_tiles.hip process_entry), one dependent chain per trip:
+// 4 independent "quadrants" per trip to mimic the kernel's unrolled k loop without branches
+template <int WHICH>
+__global__ void __launch_bounds__(256) blk(float* out, uint64_t* ticks, int iters) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const float l = threadIdx.x & 63;
+  f2 pix[4]; float Ts[4], C2[4]; f2 C01[4]; uint32_t last[4];
+  float T[4], acc2[4], g2[4], Tfb[4]; f2 acc01[4], g01[4]; uint32_t nc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    pix[q] = f2{(float)((int)l & 7) + 8.f * (q & 1), (float)((int)l >> 3) + 8.f * (q >> 1)};
+    Ts[q] = 1.f; C2[q] = 0.f; C01[q] = f2{0.f, 0.f}; last[q] = 0;
+    T[q] = 0.3f; acc2[q] = 0.f; acc01[q] = f2{0.f, 0.f}; g01[q] = f2{0.1f, 0.2f}; g2[q] = 0.3f; Tfb[q] = 0.01f; nc[q] = 1u << 30;
+  }
+  float gx = 7.5f + 0.01f * blockIdx.x, gy = 8.5f, A = -0.02f, B = 0.001f, Cq = -0.03f, o = 0.5f;
+  float c0 = 0.5f, c1 = 0.25f, c2 = 0.125f;
+  const float amax = 0.99f, amin = 1.f / 255.f, tmin = 1e-4f;
+  float Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, s_op = 0, s_b = 0; f2 s_rg = {0, 0};
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t hidx = (uint32_t)it + 1u;
+    gx += 1e-4f;            // keep the compiler from hoisting the geometry
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f2 dd = f2{gx, gy} - pix[q];
+      const f2 bc = f2{B, Cq} * f2{dd.y, dd.y};
+      const float pw = fmaf(dd.x, fmaf(A, dd.x, bc.x), dd.y * bc.y);
+      if (WHICH == 0) {
+        const float alpha = fminf(amax, o * __builtin_amdgcn_exp2f(pw));
+        const bool ok = (pw <= 0.f) & (alpha >= amin);
+        const float ale = ok ? alpha : 0.f;
+        float Tp;
+        asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[q]));
+        const f2 tw = f2{Tp, Tp} * f2{1.f - ale, ale};
+        const bool stop = tw.x < tmin;
+        const float wgt = stop ? 0.f : tw.y;
+        Ts[q] = stop ? -fabsf(Ts[q]) : tw.x;
+        C01[q] = f2{c0, c1} * f2{wgt, wgt} + C01[q];
+        C2[q] = fmaf(c2, wgt, C2[q]);
+        last[q] = (ok & !stop) ? hidx : last[q];
+      } else {
+        const float Gv = __builtin_amdgcn_exp2f(pw);
+        float alpha;
+        asm("v_min_f32 %0, %1, %2" : "=v"(alpha) : "s"(amax), "v"(o * Gv));
+        const bool ok = (hidx <= nc[q]) & (pw <= 0.f) & (alpha >= amin);
+        const float ale = ok ? alpha : 0.f;
+        const float rcp = __builtin_amdgcn_rcpf(1.f - ale);
+        const float Tn = T[q] * rcp;
+        const f2 d01 = f2{c0, c1} - acc01[q];
+        const float d2 = c2 - acc2[q];
+        const f2 t01 = d01 * g01[q];
+        float dLda = fmaf(d2, g2[q], t01.x + t01.y) * Tn;
+        dLda = fmaf(Tfb[q], rcp, dLda);
+        const float dch = ale * Tn;
+        s_rg = f2{dch, dch} * g01[q] + s_rg;
+        s_b = fmaf(dch, g2[q], s_b);
+        const float gda = ok ? Gv * dLda : 0.f;
+        s_op += gda;
+        const float qq = o * gda;
+        const f2 qxy = f2{qq, qq} * dd;
+        Mx += qxy.x; My += qxy.y;
+        Mxx = fmaf(qxy.x, dd.x, Mxx); Mxy = fmaf(qxy.x, dd.y, Mxy);
+        Myy = fmaf(qxy.y, dd.y, Myy);
+        T[q] = Tn * 0.999f + 0.0003f;      // (keeps T bounded over the loop; one extra fma)
+        acc01[q] = f2{ale, ale} * d01 + acc01[q];
+        acc2[q] = fmaf(ale, d2, acc2[q]);
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float s = Mx + My + Mxx + Mxy + Myy + s_op + s_b + s_rg.x + s_rg.y;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s += Ts[q] + C2[q] + C01[q].x + C01[q].y + (float)last[q] + T[q] + acc2[q] + acc01[q].x + acc01[q].y;
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+static float* g_out; static uint64_t* g_ticks;
+
+template <typename K>
+void timeit(const char* name, K kern, int w, double inst_per_iter, int iters) {
+  const int blocks = 256 * w;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, g_out, g_ticks, iters);
+  hipEventRecord(a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, g_out, g_ticks, iters);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  uint64_t ticks; hipMemcpy(&ticks, g_ticks, 8, hipMemcpyDeviceToHost);
+  const double inst_per_simd = (double)iters * inst_per_iter * w;   // one wave of each block per SIMD
+  const double mhz = (double)ticks / (ms * 1e3);                    // s_memtime ticks per microsecond
+  printf("%-34s w=%d  %8.3f ms  memtime %7.1f MHz  %.2f cyc/inst @2.4GHz  %.2f ticks/inst\n", name, w, ms, mhz,
+         2400.0 * ms * 1e3 / inst_per_simd, (double)ticks / inst_per_simd);
+}
+
+#define RUN(OP, NAME, N) for (int w : {1, 4, 8}) timeit(NAME, k<OP>, w, 32.0 * N, 6000)
+int main() {
+  hipMalloc(&g_out, 256 * 8 * 256 * 4); hipMalloc(&g_ticks, 64);
+  RUN(0, "v_fma_f32 (VOP3, 3 regs)", 1);  RUN(1, "v_mul_f32_e32", 1);  RUN(2, "v_fmac_f32_e32", 1);
+  RUN(3, "v_pk_fma_f32", 1);  RUN(4, "v_pk_mul_f32", 1);  RUN(5, "v_pk_add_f32", 1);
+  RUN(6, "v_exp_f32", 1);  RUN(7, "v_rcp_f32", 1);
+  RUN(8, "v_cndmask_b32_e32 (vcc)", 1);  RUN(9, "v_cndmask_b32_e64 (sgpr pair)", 1);
+  RUN(10, "v_cmp_lt_f32_e32 -> vcc", 1);  RUN(11, "v_cmp_lt_f32_e64 -> sgpr pair", 1);
+  RUN(12, "v_min_f32_e32", 1);  RUN(13, "v_add_f32_dpp row_shr:1", 1);  RUN(14, "v_permlane32_swap", 1);
+  RUN(15, "v_max3_f32", 1);  RUN(16, "v_sub_f32_e32 1.0 - x", 1);  RUN(17, "v_mov_b32", 1);
+  RUN(18, "v_cndmask_e64 with -|x|", 1);  RUN(19, "v_cmp_e32 + v_cndmask_e32 pair", 2);
+  RUN(20, "v_fmac_e32 + v_mul_e32 pair", 2);
+  for (int w : {1, 2, 4, 8}) timeit("forward block x4 quadrants / trip", blk<0>, w, 4.0, 20000);
+  for (int w : {1, 2, 4}) timeit("backward block x4 quadrants / trip", blk<1>, w, 4.0, 20000);
+  return 0;
+}

@@ -13,7 +13,10 @@ a SIMD), so  valu_busy_ms = ACTIVE_INST_VALU * 4 / (1024 SIMDs * 2.4e6 cycles/ms
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -29,7 +32,8 @@ def main():
         if "SQ_ACTIVE_INST_VALU" in row:
             row["valu_busy_ms_at_2.4GHz"] = round(row["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * 2.4e6), 4)
         out[k] = row
-    json.dump(dict(unit="mean counter value per launch", kernels=out), sys.stdout, indent=1)
+    from build_stamp import stamp
+    json.dump(dict(unit="mean counter value per launch", **stamp(), kernels=out), sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

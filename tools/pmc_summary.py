@@ -12,7 +12,10 @@ reads (colour forward: 431 811 KB reported for 826 MB of SH + 44 MB of radii), W
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def load(path):
     per = collections.defaultdict(list)
@@ -32,8 +35,9 @@ def main():
         kernels[k.replace("void ", "")] = dict(
             fetch_kb=round(f, 1), write_kb=round(w, 1), launches_profiled=n,
             bytes=round((2.0 * f + w) * 1024.0))
+    from build_stamp import stamp
     json.dump(dict(unit="mean KB per launch; bytes = (2 x fetch_kb + write_kb) x 1024",
-                   kernels=kernels), sys.stdout, indent=1)
+                   **stamp(), kernels=kernels), sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
