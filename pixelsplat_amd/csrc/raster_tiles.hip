@@ -20,23 +20,26 @@
 #include "raster_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef PS_ABLATE
 #define PS_ABLATE 0   // 1..3: timing experiments that drop part of a tile kernel's work (results invalid)
 #endif
-// Experiment, not in the default build and not yet run on hardware (tools/build_variant.sh x
-// -DPS_BWD_STAGED_SUMS=1; validate with the raster GPU tests through PIXELSPLAT_HIP_LIB): the
-// backward's nine per-entry sums stop one DPP step early -- 8-lane partial sums, 24 floats per entry --
-// and are staged in LDS; the lane that finalises the entry adds the halves.  Per contributing entry
-// 9 DPP adds instead of 14, no flag traffic (the "entry contributed" bits stay in an SGPR), at the
-// price of finalising every 32 instead of every 64 entries.  Ablation says the reduction and its
-// hand-over are 26 % of the kernel.
-#ifndef PS_BWD_STAGED_SUMS
-#define PS_BWD_STAGED_SUMS 0
+// Quadrants per forward wave: 4 = one wave per 16x16 tile (4 pixels per lane); 2 = two waves per tile
+// (top / bottom half, 2 pixels per lane); 1 = one wave per 8x8 quadrant.  Fewer quadrants per wave =
+// more, smaller tasks (the launch tail of 7168 tile tasks on 4096 wave slots costs the 4-quadrant
+// kernel ~14 % at BASELINE configs[1]) and fewer registers (more waves per SIMD), paid for with a
+// refine pass per wave over the tile's whole list.  Results are identical by construction (a
+// pixel's walk does not depend on which wave owns it).
+#ifndef PS_FWD_QW
+#define PS_FWD_QW 4
 #endif
 
 namespace ps {
 
+constexpr int kFwdQW = PS_FWD_QW;
+constexpr int kFwdParts = 4 / kFwdQW;
+static_assert(kFwdQW == 1 || kFwdQW == 2 || kFwdQW == 4, "PS_FWD_QW must be 1, 2 or 4");
 constexpr int kBatch = 64;
 constexpr int kQB = 128;            // ring B capacity (>= 63 + 64), power of two
 constexpr int kWavesPerBlock = 4;      // forward: tiles (waves) per block
@@ -50,16 +53,16 @@ constexpr float kLog2e = 1.4426950408889634f;
 struct WaveLds {
   float4 rec[kQB][3];               // {gx,gy,A,B} {C,opacity,r,g} {b,list index,quad mask,id}
 };
-#if PS_BWD_STAGED_SUMS
+// The backward's nine per-entry sums stop one DPP step early -- 8-lane partial sums, 24 floats per
+// entry -- and are staged in LDS; the lane that finalises the entry adds the halves.  Per
+// contributing entry 9 DPP adds instead of 14 and no flag traffic (the "entry contributed" bits stay
+// in an SGPR), at the price of finalising every 32 instead of every 64 entries: tiles_backward
+// 1.81 -> 1.75 ms at BASELINE configs[1] (profiles/r3_variants_ab.txt; round 2 had the full 64-lane sums
+// and a per-entry flag in LDS).
 constexpr int kStage = 32;              // entries per finalisation batch
 struct WaveLdsBwd : WaveLds {
   float stage[kStage][3][8];            // per entry: r1, r2, s_b as 8-lane partial sums
 };
-#else
-struct WaveLdsBwd : WaveLds {
-  float gsum[kBatch][kGradFloats + 1];  // per-entry reduced sums (+ "touched" flag)
-};
-#endif
 
 __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 #pragma unroll
@@ -137,6 +140,41 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, f
   return m;
 }
 
+// Per-entry "plain" flag (wave-uniform when the entry is blended): the conic is positive definite
+// with a condition number far from fp32 round-off (so `power > 0` cannot happen for any pixel: the
+// true power is <= -lambda_min |d|^2 and its fp32 evaluation is off by < 4e-7 lambda_max |d|^2) and the
+// opacity is below the alpha_max clamp.  Such an entry needs neither the per-pixel sign test of the
+// power nor the min() -- two of the half-rate compare / select class instructions the blend loops are
+// made of (tools/issue_model.hip: v_cmp / v_cndmask / v_min / DPP issue at ~4.4 cycles per wave64
+// instruction, v_fma / v_mul / v_add at ~2.9) -- and skipping them changes no result.
+constexpr uint32_t kPlainBit = 32u;
+__device__ __forceinline__ bool entry_is_plain(float gx, float gy, float A, float B, float Cq,
+                                               float opacity, float alpha_max) {
+  const float det = 4.f * A * Cq - B * B, tr = A + Cq;
+  const bool finite = fabsf(gx) < 1e30f && fabsf(gy) < 1e30f && fabsf(tr) < 1e30f && fabsf(B) < 1e30f;
+  return finite && A < 0.f && Cq < 0.f && det > 1e-4f * tr * tr && opacity <= 0.98f * alpha_max &&
+         opacity >= 0.f;
+}
+
+// the same for the QW quadrants first .. first + QW - 1 of the tile only (bit k: quadrant first + k)
+template <int QW>
+__device__ __forceinline__ uint32_t quadrant_mask_part(float gx, float gy, float A, float B,
+                                                       float Cq, float opacity, float alpha_min,
+                                                       float x0, float y0, int first) {
+  const float tau = __log2f(opacity / alpha_min);
+  if (!(tau >= 0.f)) return 0u;
+  const float det = 4.f * A * Cq - B * B;
+  if (!(A < 0.f && Cq < 0.f && det > 0.f)) return (1u << QW) - 1u;
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < QW; ++k) {
+    const int q = first + k;
+    if (quad_may_contribute(gx, gy, A, B, Cq, tau, x0 + 8.f * (q & 1), y0 + 8.f * (q >> 1)))
+      m |= 1u << k;
+  }
+  return m;
+}
+
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
@@ -153,7 +191,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   * the refine's two dependent global latencies (list -> record gather) are off the wave's critical
 //     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
 //     is refined and blended.
-__global__ void __launch_bounds__(kWavesPerBlock* kWave)
+#ifndef PS_FWD_MIN_WAVES
+#define PS_FWD_MIN_WAVES (PS_FWD_QW == 4 ? 4 : 6)   // waves per SIMD the register allocation aims at
+#endif
+__global__ void __launch_bounds__(kWavesPerBlock* kWave, PS_FWD_MIN_WAVES)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ tile_order,
                      const uint32_t* __restrict__ tile_ranges,
@@ -161,6 +202,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const float* __restrict__ view_params, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                      uint32_t* __restrict__ tile_end) {
+  constexpr int QW = kFwdQW;          // quadrants (= pixels per lane) of this wave
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int G = d.n_gaussians, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
@@ -168,8 +210,10 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int V = d.n_scenes * d.views_per_scene;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot_global = blockIdx.x * kWavesPerBlock + w;
-  if (slot_global >= V * tiles) return;
-  const int tile_global = (int)tile_order[slot_global];   // longest lists are launched first
+  if (slot_global >= V * tiles * kFwdParts) return;
+  // longest lists are launched first; the parts of a tile are neighbours in the launch order
+  const int tile_global = (int)tile_order[slot_global / kFwdParts];
+  const int q_first = (slot_global % kFwdParts) * QW;     // first quadrant of this wave
   WaveLds& lds = lds_all[w];
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
@@ -179,74 +223,156 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
   if (l_start > capacity) l_start = capacity;                       // overflowed step: stay in
   if (l_count > capacity - l_start) l_count = capacity - l_start;   // bounds (flag is raised)
+  // (loaded with vector loads: tell the compiler they are wave-uniform, or every loop bounded by
+  // them is compiled as divergent control flow)
+  l_start = __builtin_amdgcn_readfirstlane(l_start);
+  l_count = __builtin_amdgcn_readfirstlane(l_count);
   const uint32_t* list = point_list + l_start;
 
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  int px[4], py[4]; float pxf[4], pyf[4]; bool live[4];
-  float T[4], C0[4], C1[4], C2[4]; uint32_t last[4];
+  int px[QW], py[QW]; float pxf[QW], pyf[QW]; bool live[QW];
+  float T[QW], C0[QW], C1[QW], C2[QW]; uint32_t last[QW];
+  bool any_live = false;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    px[k] = tx * kTile + 8 * (k & 1) + (lane & 7);
-    py[k] = ty * kTile + 8 * (k >> 1) + (lane >> 3);
+  for (int k = 0; k < QW; ++k) {
+    const int q = q_first + k;
+    px[k] = tx * kTile + 8 * (q & 1) + (lane & 7);
+    py[k] = ty * kTile + 8 * (q >> 1) + (lane >> 3);
     pxf[k] = (float)px[k]; pyf[k] = (float)py[k];
     live[k] = px[k] < W && py[k] < H;
+    any_live |= live[k];
     T[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f; last[k] = 0;
   }
   uint32_t b_head = 0, b_tail = 0;  // wave-uniform ring cursors
   const uint64_t lt = lanemask_lt();
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min, t_min = d.t_min;
-  bool all_done = !__any(live[0] | live[1] | live[2] | live[3]);
+  bool all_done = !__any(any_live);
 
   // Ts[k] = T while the pixel is live, -T once it has stopped (pixels outside the image start
   // stopped)
-  float Ts[4];
+  float Ts[QW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) Ts[k] = live[k] ? 1.f : -1.f;
-  // one ring entry against the (up to four) quadrants it can reach
-  auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
+  for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
+  // Stop-free windows.  A pixel can only stop at an entry when T (1 - alpha) < t_min, alpha <= the
+  // entry's opacity: with om = the largest opacity among the ring's entries, no pixel with
+  // T >= t_floor = t_min / (1 - om)^8 can stop within the next 8 entries.  Every 8 entries ONE compare
+  // per quadrant asks "is every pixel of the wave live with T >= t_floor"; if so, and if the ring holds
+  // plain entries only (entry_is_plain), the window's 8 entries take the short form of the update: no
+  // sign test of the power, no alpha_max clamp, no max(T, 0), no stop test, no selects on the weight and
+  // the transmittance -- 14 full-rate + 3 half-rate + 1 transcendental instruction per quadrant
+  // evaluation instead of 9 + 9 + 1 + 4 packed: ~62 instead of ~84 issue cycles
+  // (profiles/r3_issue_model.txt).  The decision is per window and per wave, not per entry or quadrant:
+  // two forms inside one loop body cost register copies at every join.  84 % of the quadrant
+  // evaluations of BASELINE configs[1] lie in such windows (opacities <= 1/3: t_floor = 2.5e-3).
+  float om_run = 0.f, t_floor = __builtin_inff();   // largest opacity in the ring; the windows' floor
+  bool plain_run = true;                             // every entry in the ring is plain
+  auto all_quadrants_stop_free = [&]() {       // every pixel of the wave: live, T >= t_floor
+    bool below = false;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) below |= Ts[k] < t_floor;     // (Ts < 0: stopped)
+    return !__any(below);
+  };
+  // one ring entry against the (up to QW) quadrants of this wave it can reach; FAST: the short form
+  // (the caller has established a stop-free window and a ring of plain entries)
+  auto process_entry = [&](auto fast_tag, const float4 q0, const float4 q1, const float4 q2) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const uint32_t hidx = __float_as_uint(q2.y);
 #if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
 #else
-    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+    // (one quadrant per wave: every ring entry reaches it, no mask to test)
+    const uint32_t qm = QW == 1 ? 1u : __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #endif
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < QW; ++k) {
       if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
-        const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
-        const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
-        const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
-        const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
-        const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
-        const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-        float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
-        asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
-        const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
-        const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
-        const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
-        Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
-        C0[k] = fmaf(q1.z, wgt, C0[k]);
-        C1[k] = fmaf(q1.w, wgt, C1[k]);
-        C2[k] = fmaf(q2.x, wgt, C2[k]);
-        last[k] = (ok & !stop) ? hidx : last[k];
+        if (FAST) {
+          // The short form, instruction for instruction (left to the compiler the same source
+          // came out with a second compare and register copies around it): 14 full-rate
+          // mul / add / fma class instructions, one v_exp, one compare and two selects; every
+          // per-pixel value is updated in place.
+          float dx, dy, t, u;
+          asm volatile(
+              "v_sub_f32 %[dx], %[gx], %[px]\n"
+              "v_sub_f32 %[dy], %[gy], %[py]\n"
+              "v_mul_f32 %[t], %[B], %[dy]\n"
+              "v_mul_f32 %[u], %[C], %[dy]\n"
+              "v_fmac_f32 %[t], %[A], %[dx]\n"          // A dx + B dy
+              "v_mul_f32 %[u], %[u], %[dy]\n"           // C dy^2
+              "v_fmac_f32 %[u], %[dx], %[t]\n"          // power * log2(e)  (<= 0: entry_is_plain)
+              "v_exp_f32 %[u], %[u]\n"
+              "s_nop 0\n"                              // trans -> non-trans VALU use of the result
+              "v_mul_f32 %[u], %[o], %[u]\n"            // alpha  (< alpha_max: entry_is_plain)
+              "v_cmp_le_f32 vcc, %[amin], %[u]\n"
+              "v_cndmask_b32 %[u], 0, %[u], vcc\n"      // alpha or 0
+              "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
+              "v_mul_f32 %[t], %[T], %[u]\n"            // T alpha
+              "v_sub_f32 %[dx], 1.0, %[u]\n"
+              "v_mul_f32 %[T], %[T], %[dx]\n"           // T (1 - alpha)  (> 0: stop-free window)
+              "v_fmac_f32 %[c0], %[r], %[t]\n"
+              "v_fmac_f32 %[c1], %[g], %[t]\n"
+              "v_fmac_f32 %[c2], %[b], %[t]\n"
+              : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [T] "+v"(Ts[k]),
+                [c0] "+v"(C0[k]), [c1] "+v"(C1[k]), [c2] "+v"(C2[k]), [last] "+v"(last[k])
+              : [gx] "v"(q0.x), [gy] "v"(q0.y), [A] "v"(q0.z), [B] "v"(q0.w), [C] "v"(q1.x),
+                [o] "v"(q1.y), [r] "v"(q1.z), [g] "v"(q1.w), [b] "v"(q2.x), [hidx] "v"(hidx),
+                [px] "v"(pxf[k]), [py] "v"(pyf[k]), [amin] "s"(alpha_min)
+              : "vcc");
+        } else {
+          const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
+          const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
+          const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
+          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+          const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
+          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+          float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
+          asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
+          const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
+          const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
+          const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
+          Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
+          C0[k] = fmaf(q1.z, wgt, C0[k]);
+          C1[k] = fmaf(q1.w, wgt, C1[k]);
+          C2[k] = fmaf(q2.x, wgt, C2[k]);
+          last[k] = (ok & !stop) ? hidx : last[k];
+        }
       }
     }
   };
   auto every_pixel_stopped = [&]() {
-    return !__any((Ts[0] > 0.f) | (Ts[1] > 0.f) | (Ts[2] > 0.f) | (Ts[3] > 0.f));
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < QW; ++k) any |= Ts[k] > 0.f;
+    return !__any(any);
   };
-  auto blend1 = [&](uint32_t m) {
-    uint32_t slot = b_head & (kQB - 1);
-    float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-    for (uint32_t j = 0; j < m; j += 2) {
-      slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
+  // 8 ring entries (one window) from entry j0 of the current blend call, two per trip, each one's
+  // record read from LDS while the other is blended; a0..a2 hold entry j0's record on entry and
+  // entry jend's on return
+  float4 a0, a1, a2;
+  auto window = [&](auto fast_tag, uint32_t j0, uint32_t jend) {
+    for (uint32_t j = j0; j < jend; j += 2) {
+      uint32_t slot = (b_head + j + 1) & (kQB - 1);       // (stale beyond the call's m: never processed)
       const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-      process_entry(a0, a1, a2);
-      if (j + 1 >= m) break;
+      process_entry(fast_tag, a0, a1, a2);
+      if (j + 1 >= jend) break;
       slot = (b_head + j + 2) & (kQB - 1);
       a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-      process_entry(b0, b1, b2);
-      if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
+      process_entry(fast_tag, b0, b1, b2);
+    }
+  };
+  auto blend1 = [&](uint32_t m) {
+    const uint32_t slot = b_head & (kQB - 1);
+    a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
+    const bool ring_plain = plain_run;
+    for (uint32_t j0 = 0; j0 < m; j0 += 8) {
+      const uint32_t jend = j0 + 8 < m ? j0 + 8 : m;
+      // ONE compare per quadrant decides the form of the next 8 entries (see above)
+      if (ring_plain && all_quadrants_stop_free()) {
+        window(std::true_type{}, j0, jend);
+      } else {
+        window(std::false_type{}, j0, jend);
+        if (every_pixel_stopped()) { all_done = true; break; }
+      }
     }
     b_head += m;
     wave_lds_sync();
@@ -273,29 +399,51 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
         gather(id2, n0, n1, n2);
         id2 = idx_of(first + 2 * kBatch);
       }
-      bool keep = false;
+      bool keep = false, not_plain = false;
+      float op_keep = 0.f;
       float4 q0, q1, q2;
       if ((uint32_t)lane < m) {
         const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
-        const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
+        const uint32_t qm = QW == 4 ? quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0)
+                                    : quadrant_mask_part<QW>(r0.x, r0.y, A, B, Cq, r1.y, alpha_min,
+                                                             x0, y0, q_first);
         keep = qm != 0u;
+        not_plain = keep && !entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max);
         q0 = make_float4(r0.x, r0.y, A, B);
         q1 = make_float4(Cq, r1.y, r2.x, r2.y);
         q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
+        op_keep = keep ? r1.y : 0.f;
       }
       const uint64_t mask = __ballot(keep);
       if (keep) {
         const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
         lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
       }
+      const bool ring_was_empty = b_tail == b_head;
       b_tail += (uint32_t)__popcll(mask);
+      // largest opacity / "all plain" over the entries the ring holds: running values, reset when
+      // the ring runs empty (leftovers can outlive several refine batches that kept nothing)
+      if (ring_was_empty) { om_run = 0.f; plain_run = true; }
+      plain_run = plain_run && !__any(not_plain);
+      om_run = fmaxf(om_run, __uint_as_float(wave_max_u(__float_as_uint(op_keep))));   // (>= 0: bits order)
+      {
+        const float om = fminf(om_run, alpha_max);
+        // t_min / (1 - om)^8, rounded up a little; om -> 1 gives +inf (never stop-free)
+        t_floor = 1.0001f * t_min * fast_exp2(-8.f * __log2f(1.f - om));
+        t_floor = (t_floor == t_floor) ? t_floor : __builtin_inff();
+      }
       wave_lds_sync();
-      while (!all_done && b_tail - b_head >= (uint32_t)kBatch) blend1(kBatch);
+      // full batches while the list lasts, then whatever is left (ONE call site: the blend loop
+      // is instantiated once)
+      const bool last_batch = first + kBatch >= l_count;
+      while (!all_done && (b_tail - b_head >= (uint32_t)kBatch || (last_batch && b_tail != b_head))) {
+        const uint32_t have = b_tail - b_head;
+        blend1(have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
+      }
     }
   }
-  if (!all_done && b_tail != b_head) blend1(b_tail - b_head);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) T[k] = fabsf(Ts[k]);
+  for (int k = 0; k < QW; ++k) T[k] = fabsf(Ts[k]);
 
   // epilogue
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
@@ -303,7 +451,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const size_t P = (size_t)H * W;
   uint32_t max_c = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < QW; ++k) {
     if (px[k] < W && py[k] < H) {
       const size_t pix = (size_t)py[k] * W + px[k];
       float* oc = out_color + (size_t)v * 3 * P;
@@ -315,8 +463,12 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       max_c = last[k] > max_c ? last[k] : max_c;
     }
   }
-  max_c = wave_max_u(max_c);
-  if (lane == 0) tile_end[tile_global] = max_c;
+  // the tile's last contributor (informational since the backward derives it from n_contrib;
+  // with several waves per tile only the one-wave-per-tile build writes it)
+  if (QW == 4) {
+    max_c = wave_max_u(max_c);
+    if (lane == 0) tile_end[tile_global] = max_c;
+  }
 }
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
@@ -326,7 +478,7 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
                           hipStream_t st) {
   const Dims m = make_dims(d);
-  const int total = m.V * m.tiles;
+  const int total = m.V * m.tiles * kFwdParts;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
   hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
                      point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
@@ -351,34 +503,6 @@ __device__ __forceinline__ float fold16(float x, float y) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);       // rows [x0+x1, y0+y1, x2+x3, y2+y3]
 }
-__device__ __forceinline__ void wave_sum9_rows(float a, float b, float c, float d, float e,
-                                               float f, float g, float h, float& i, float& r1,
-                                               float& r2) {
-  r1 = fold16(fold32(a, b), fold32(c, d));
-  r2 = fold16(fold32(e, f), fold32(g, h));
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "s_nop 1\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "s_nop 1\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "s_nop 1\n"
-      : "+v"(r1), "+v"(r2), "+v"(i));
-}
-
-#if PS_BWD_STAGED_SUMS
 // the nine sums down to 8-lane partials: r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]
 // (as in wave_sum9_rows), i = s_b; afterwards lanes 7 and 15 of every 16-lane row hold the sums of
 // lanes 0-7 and 8-15 of that row
@@ -401,7 +525,6 @@ __device__ __forceinline__ void wave_sum9_partials(float a, float b, float c, fl
       "s_nop 1\n"
       : "+v"(r1), "+v"(r2), "+v"(i));
 }
-#endif
 
 // The loop is the last of the round-2 A/B series (profiles/r2_tiles_variants_ab.txt: 2.14 -> 1.82 ms at
 // BASELINE configs[1]; the superseded variants are in the history before this commit): the record is read
@@ -436,12 +559,27 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   float* gacc = grad2d + vo * kGradFloats;
   uint32_t l_start = tile_ranges[2 * (size_t)tile_global];
   if (l_start > capacity) l_start = capacity;
+  l_start = __builtin_amdgcn_readfirstlane(l_start);       // (wave-uniform: say so)
   const uint32_t* list = point_list + l_start;
 
   // entries behind the tile's last contributor are never blended (1-based index c_max); the
   // geometry backward still sums the private slot of every (Gaussian, tile) pair of a small
   // Gaussian, so the slots of those entries are cleared here (nothing is memset)
-  const uint32_t c_max = tile_end[tile_global];
+  // the tile's last contributor = max of its pixels' n_contrib (derived here: with several forward
+  // waves per tile no single wave knows it; 5 extra loads per lane, off the critical path)
+  uint32_t c_max = 0;
+  {
+    const size_t Pn = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int px = tx * kTile + 8 * (k & 1) + (lane & 7);
+      const int py = ty * kTile + 8 * (k >> 1) + (lane >> 3);
+      const uint32_t n = (px < W && py < H) ? n_contrib[(size_t)v * Pn + (size_t)py * W + px] : 0u;
+      c_max = n > c_max ? n : c_max;
+    }
+    c_max = __builtin_amdgcn_readfirstlane(wave_max_u(c_max));   // (wave-uniform: say so)
+  }
+  (void)tile_end;
   float4* const slots = reinterpret_cast<float4*>(tile_grads) + vo * (kInvSlots * kSlotVec);
   {
     uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
@@ -500,8 +638,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     return (uint32_t)lane < top ? list[top - 1u - lane] : list[0];
   };
   uint32_t id_ahead = c_max > 0 ? idx_of(c_max) : 0u;
+  bool plain_run = true;                       // every entry in the ring is plain
   auto refine = [&](uint32_t top, uint32_t m) {
-    bool keep = false;
+    bool keep = false, not_plain = false;
     float4 q0, q1, q2;
     const uint32_t id_now = id_ahead;
     if (top > m) id_ahead = idx_of(top - m);
@@ -530,7 +669,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       }
       q2 = make_float4(r2.z, __uint_as_float(top - lane), __uint_as_float(qm | small),
                        __uint_as_float(target));
+      not_plain = keep && !entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max);
     }
+    if (b_tail == b_head) plain_run = true;      // running flag over the ring, reset when it is empty
+    plain_run = plain_run && !__any(not_plain);
     const uint64_t mask = __ballot(keep);
     if (keep) {
       const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
@@ -540,11 +682,16 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     wave_lds_sync();
   };
 
-#if PS_BWD_STAGED_SUMS
-  uint32_t hitbits = 0;   // bit j: entry j of the finalisation batch contributed
-#endif
-  // one ring entry: the pixels' updates, the nine wave sums, their hand-over through LDS
-  auto entry = [&](uint32_t j, const float4 q0, const float4 q1, const float4 q2) {
+  uint32_t hitbits = 0;   // bit j: entry j of the finalisation batch contributed (wave-uniform)
+  // one ring entry: the pixels' updates, the nine wave sums down to 8-lane partials, staged in LDS.
+  // FAST (decided per blend call, see blend()): every entry of the call is plain (entry_is_plain:
+  // no sign test of the power, no alpha_max clamp) and lies at or before EVERY pixel's last
+  // contributor (no `hidx <= n_contrib` test), and alpha = opacity * G lets q = opacity * G * dL/dalpha
+  // be formed as alpha * dL/dalpha without the select on G dL/dalpha: five of the half-rate compare /
+  // select class instructions and a multiply less per quadrant evaluation (tools/issue_model.hip).
+  // The opacity sum then holds sum(q) = opacity * sum(G dL/dalpha); the finalising lane divides.
+  auto entry = [&](auto fast_tag, uint32_t j, const float4 q0, const float4 q1, const float4 q2) {
+      constexpr bool FAST = decltype(fast_tag)::value;
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
 #if PS_ABLATE == 2   // timing experiment: no per-pixel math (and so no reduction)
@@ -565,9 +712,15 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};        // (B dy, C dy)
             const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);
             const float Gv = fast_exp2(pw);
-            float alpha;                                   // min(alpha_max, o G) in one instruction
-            asm("v_min_f32 %0, %1, %2" : "=v"(alpha) : "s"(alpha_max), "v"(o * Gv));
-            const bool ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
+            float alpha;
+            bool ok;
+            if (FAST) {
+              alpha = o * Gv;
+              ok = alpha >= alpha_min;
+            } else {                                         // min(alpha_max, o G) in one instruction
+              asm("v_min_f32 %0, %1, %2" : "=v"(alpha) : "s"(alpha_max), "v"(o * Gv));
+              ok = (hidx <= nc[k]) & (pw <= 0.f) & (alpha >= alpha_min);
+            }
             const float ale = ok ? alpha : 0.f;            // 0 => all updates are no-ops
             const float rcp = __builtin_amdgcn_rcpf(1.f - ale);   // 1 ulp; exact 1 when ale == 0
             const float Tn = T[k] * rcp;                    // T in front of this entry
@@ -579,9 +732,15 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const float dch = ale * Tn;
             s_rg = f32x2{dch, dch} * g01[k] + s_rg;
             s_b = fmaf(dch, g2[k], s_b);
-            const float gda = ok ? Gv * dL_dalpha : 0.f;    // G * dL/dalpha
-            s_op += gda;
-            const float q = o * gda;                        // G * dL/dG
+            float q;                                        // opacity * G * dL/dalpha = G * dL/dG
+            if (FAST) {
+              q = ale * dL_dalpha;
+              s_op += q;
+            } else {
+              const float gda = ok ? Gv * dL_dalpha : 0.f;  // G * dL/dalpha
+              s_op += gda;
+              q = o * gda;
+            }
             const f32x2 qxy = f32x2{q, q} * dd;             // (q dx, q dy)
             M1 += qxy;
             M2 = f32x2{qxy.x, qxy.x} * dd + M2;             // (Mxx, Mxy) += q dx (dx, dy)
@@ -600,7 +759,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
 #else
       if (__any(any)) {
 #endif
-#if PS_BWD_STAGED_SUMS
+        // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         float r1, r2;
         wave_sum9_partials(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);
         if ((lane & 7) == 7) {
@@ -609,129 +768,96 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         }
         hitbits |= 1u << j;                 // wave-uniform: stays in an SGPR
       }
-#else
-        // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
-        float r1, r2;
-        wave_sum9_rows(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);
-        if ((lane & 15) == 15) {
-          // row r of r1 holds value {0, 2, 1, 3}[r], row r of r2 value 4 + {0, 2, 1, 3}[r]
-          const int row = lane >> 4, idx = ((row & 1) << 1) | (row >> 1);
-          float* gs = lds.gsum[j];
-          gs[idx] = r1; gs[4 + idx] = r2;
-          if (lane == 63) { gs[8] = s_b; gs[9] = 1.f; }
-        }
-      } else if (lane == 63) {
-        lds.gsum[j][9] = 0.f;
-      }
-#endif
   };
 
-#if PS_BWD_STAGED_SUMS
-  auto blend = [&](uint32_t m) {
-    for (uint32_t base = 0; base < m; base += kStage) {
-      const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
-      hitbits = 0;
-      {
-        uint32_t slot = (b_head + base) & (kQB - 1);
-        float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-        for (uint32_t j = 0; j < cnt; j += 2) {
-          slot = (b_head + base + j + 1) & (kQB - 1);          // (stale beyond cnt: never processed)
-          const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-          entry(j, a0, a1, a2);
-          if (j + 1 >= cnt) break;
-          slot = (b_head + base + j + 2) & (kQB - 1);
-          a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-          entry(j + 1, b0, b1, b2);
-        }
-      }
-      wave_lds_sync();
-      if ((uint32_t)lane < cnt) {
-        const uint32_t slot = (b_head + base + lane) & (kQB - 1);
-        const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
-        const float4* sp = reinterpret_cast<const float4*>(&lds.stage[lane][0][0]);
-        const float4 u0 = sp[0], u1 = sp[1], v0 = sp[2], v1 = sp[3], w0 = sp[4], w1 = sp[5];
-        const bool hit = (hitbits >> lane) & 1u;
-        // r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]; a row = two 8-lane halves
-        const float Mx = u0.x + u0.y, Mxx = u0.z + u0.w, My = u1.x + u1.y, Mxy = u1.z + u1.w;
-        const float Myy = v0.x + v0.y, s_r = v0.z + v0.w, s_op = v1.x + v1.y, s_g = v1.z + v1.w;
-        const float s_b = ((w0.x + w0.y) + (w0.z + w0.w)) + ((w1.x + w1.y) + (w1.z + w1.w));
-        const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
-                    cz = q1.x * (-2.f / kLog2e);
-        const float o0 = (-cx * Mx - cy * My) * ddelx_dx, o1 = (-cz * My - cy * Mx) * ddely_dy;
-        const float o2 = -0.5f * Mxx, o3 = -0.5f * Mxy, o4 = -0.5f * Myy;
-        if (__float_as_uint(q2.z) & 16u) {
-          float4* tg = slots + (size_t)__float_as_uint(q2.w) * kSlotVec;
-          tg[0] = hit ? make_float4(o0, o1, o2, o3) : make_float4(0.f, 0.f, 0.f, 0.f);
-          tg[1] = hit ? make_float4(o4, s_op, s_r, s_g) : make_float4(0.f, 0.f, 0.f, 0.f);
-          tg[2] = make_float4(hit ? s_b : 0.f, 0.f, 0.f, 0.f);
-          if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (hit) {
-          float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
-          atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
-          atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, s_op);
-          atomicAdd(ga + 6, s_r); atomicAdd(ga + 7, s_g); atomicAdd(ga + 8, s_b);
-        }
-      }
-      wave_lds_sync();     // the staging rows are rewritten by the next batch
-    }
-    b_head += m;
-  };
-#else
-  auto blend = [&](uint32_t m) {
+  // kStage ring entries from entry `base` of the current blend call, two per trip (each one's
+  // record read from LDS while the other is processed), then lane j finalises entry j: its
+  // private slot (always written: values or zeros), or one set of 9 atomics per (tile, Gaussian)
+  // for the large ones
+  auto stage_batch = [&](auto fast_tag, uint32_t base, uint32_t cnt) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    hitbits = 0;
     {
-      // two entries per trip, each one's record read from LDS while the other is processed
-      uint32_t slot = b_head & (kQB - 1);
+      uint32_t slot = (b_head + base) & (kQB - 1);
       float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-      for (uint32_t j = 0; j < m; j += 2) {
-        slot = (b_head + j + 1) & (kQB - 1);                   // (stale beyond m: never processed)
+      for (uint32_t j = 0; j < cnt; j += 2) {
+        slot = (b_head + base + j + 1) & (kQB - 1);          // (stale beyond cnt: never processed)
         const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-        entry(j, a0, a1, a2);
-        if (j + 1 >= m) break;
-        slot = (b_head + j + 2) & (kQB - 1);
+        entry(fast_tag, j, a0, a1, a2);
+        if (j + 1 >= cnt) break;
+        slot = (b_head + base + j + 2) & (kQB - 1);
         a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-        entry(j + 1, b0, b1, b2);
+        entry(fast_tag, j + 1, b0, b1, b2);
       }
     }
     wave_lds_sync();
-    // lane j finalises entry j: its private slot (always written: values or zeros), or one set
-    // of 9 atomics per (tile, Gaussian) for the large ones
-    if ((uint32_t)lane < m) {
-      const uint32_t slot = (b_head + lane) & (kQB - 1);
+    if ((uint32_t)lane < cnt) {
+      const uint32_t slot = (b_head + base + lane) & (kQB - 1);
       const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
-      const float* gs = lds.gsum[lane];
-      const bool hit = gs[9] != 0.f;
+      const float4* sp = reinterpret_cast<const float4*>(&lds.stage[lane][0][0]);
+      const float4 u0 = sp[0], u1 = sp[1], v0 = sp[2], v1 = sp[3], w0 = sp[4], w1 = sp[5];
+      const bool hit = (hitbits >> lane) & 1u;
+      // r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]; a row = two 8-lane halves
+      const float Mx = u0.x + u0.y, Mxx = u0.z + u0.w, My = u1.x + u1.y, Mxy = u1.z + u1.w;
+      const float Myy = v0.x + v0.y, s_r = v0.z + v0.w, s_g = v1.z + v1.w;
+      float s_op = v1.x + v1.y;
+      if (FAST) s_op = s_op / q1.y;           // the fast form summed opacity * G dL/dalpha
+      const float s_b = ((w0.x + w0.y) + (w0.z + w0.w)) + ((w1.x + w1.y) + (w1.z + w1.w));
       const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
                   cz = q1.x * (-2.f / kLog2e);
-      const float Mx = gs[0], My = gs[1];
       const float o0 = (-cx * Mx - cy * My) * ddelx_dx, o1 = (-cz * My - cy * Mx) * ddely_dy;
-      const float o2 = -0.5f * gs[2], o3 = -0.5f * gs[3], o4 = -0.5f * gs[4];
+      const float o2 = -0.5f * Mxx, o3 = -0.5f * Mxy, o4 = -0.5f * Myy;
       if (__float_as_uint(q2.z) & 16u) {
         // private slot of this (Gaussian, tile): plain 16-byte stores, summed later in a fixed
         // order by the geometry backward (no atomics, deterministic)
         float4* tg = slots + (size_t)__float_as_uint(q2.w) * kSlotVec;
         tg[0] = hit ? make_float4(o0, o1, o2, o3) : make_float4(0.f, 0.f, 0.f, 0.f);
-        tg[1] = hit ? make_float4(o4, gs[5], gs[6], gs[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        tg[2] = make_float4(hit ? gs[8] : 0.f, 0.f, 0.f, 0.f);
+        tg[1] = hit ? make_float4(o4, s_op, s_r, s_g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        tg[2] = make_float4(hit ? s_b : 0.f, 0.f, 0.f, 0.f);
         if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
       } else if (hit) {
         float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
         atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
-        atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, gs[5]);
-        atomicAdd(ga + 6, gs[6]); atomicAdd(ga + 7, gs[7]); atomicAdd(ga + 8, gs[8]);
+        atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, s_op);
+        atomicAdd(ga + 6, s_r); atomicAdd(ga + 7, s_g); atomicAdd(ga + 8, s_b);
       }
     }
-    b_head += m;
-    wave_lds_sync();
+    wave_lds_sync();     // the staging rows are rewritten by the next batch
   };
-#endif
+  // the first pixel to finish: entries at or before it are inside EVERY pixel's walk (pixels outside
+  // the image count as finished at 0)
+  uint32_t nc_min;
+  {
+    uint32_t n = nc[0] < nc[1] ? nc[0] : nc[1];
+    n = nc[2] < n ? nc[2] : n;
+    n = nc[3] < n ? nc[3] : n;
+    nc_min = ~wave_max_u(~n);
+  }
+  auto blend = [&](uint32_t m) {
+    const bool ring_plain = plain_run;
+    for (uint32_t base = 0; base < m; base += kStage) {
+      const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
+      // the batch's first entry has its highest list index (the walk runs back to front)
+      const uint32_t slot = (b_head + base) & (kQB - 1);
+      const uint32_t top_h =
+          __builtin_amdgcn_readfirstlane(__float_as_uint(lds.rec[slot][2].y));
+      if (ring_plain && top_h <= nc_min) stage_batch(std::true_type{}, base, cnt);
+      else stage_batch(std::false_type{}, base, cnt);
+    }
+    b_head += m;
+  };
 
   for (uint32_t top = c_max; top > 0;) {
     const uint32_t m = top < (uint32_t)kBatch ? top : (uint32_t)kBatch;
     refine(top, m);
-    while (b_tail - b_head >= (uint32_t)kBatch) blend(kBatch);
+    // full batches while the list lasts, then whatever is left (ONE call site)
+    const bool last_batch = top == m;
+    while (b_tail - b_head >= (uint32_t)kBatch || (last_batch && b_tail != b_head)) {
+      const uint32_t have = b_tail - b_head;
+      blend(have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
+    }
     top -= m;
   }
-  if (b_tail != b_head) blend(b_tail - b_head);
 }
 
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
