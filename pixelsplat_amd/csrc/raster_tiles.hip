@@ -37,6 +37,13 @@
 
 namespace ps {
 
+#ifndef PS_NO_FAST
+#define PS_NO_FAST 0        // 1: never take the short forms (A/B of what they buy)
+#endif
+#ifndef PS_FWD_WINDOW
+#define PS_FWD_WINDOW 8     // entries per stop-free window of the forward (even)
+#endif
+constexpr int kFwdWin = PS_FWD_WINDOW;
 constexpr int kFwdQW = PS_FWD_QW;
 constexpr int kFwdParts = 4 / kFwdQW;
 static_assert(kFwdQW == 1 || kFwdQW == 2 || kFwdQW == 4, "PS_FWD_QW must be 1, 2 or 4");
@@ -255,7 +262,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
   // Stop-free windows.  A pixel can only stop at an entry when T (1 - alpha) < t_min, alpha <= the
   // entry's opacity: with om = the largest opacity among the ring's entries, no pixel with
-  // T >= t_floor = t_min / (1 - om)^8 can stop within the next 8 entries.  Every 8 entries ONE compare
+  // T >= t_floor = t_min / (1 - om)^8 can stop within the next 8 entries.  Every 8 (kFwdWin) entries ONE compare
   // per quadrant asks "is every pixel of the wave live with T >= t_floor"; if so, and if the ring holds
   // plain entries only (entry_is_plain), the window's 8 entries take the short form of the update: no
   // sign test of the power, no alpha_max clamp, no max(T, 0), no stop test, no selects on the weight and
@@ -363,9 +370,9 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   auto blend1 = [&](uint32_t m) {
     const uint32_t slot = b_head & (kQB - 1);
     a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-    const bool ring_plain = plain_run;
-    for (uint32_t j0 = 0; j0 < m; j0 += 8) {
-      const uint32_t jend = j0 + 8 < m ? j0 + 8 : m;
+    const bool ring_plain = plain_run && !PS_NO_FAST;
+    for (uint32_t j0 = 0; j0 < m; j0 += kFwdWin) {
+      const uint32_t jend = j0 + kFwdWin < m ? j0 + kFwdWin : m;
       // ONE compare per quadrant decides the form of the next 8 entries (see above)
       if (ring_plain && all_quadrants_stop_free()) {
         window(std::true_type{}, j0, jend);
@@ -429,7 +436,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       {
         const float om = fminf(om_run, alpha_max);
         // t_min / (1 - om)^8, rounded up a little; om -> 1 gives +inf (never stop-free)
-        t_floor = 1.0001f * t_min * fast_exp2(-8.f * __log2f(1.f - om));
+        t_floor = 1.0001f * t_min * fast_exp2(-(float)kFwdWin * __log2f(1.f - om));
         t_floor = (t_floor == t_floor) ? t_floor : __builtin_inff();
       }
       wave_lds_sync();
@@ -834,7 +841,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     nc_min = ~wave_max_u(~n);
   }
   auto blend = [&](uint32_t m) {
-    const bool ring_plain = plain_run;
+    const bool ring_plain = plain_run && !PS_NO_FAST;
     for (uint32_t base = 0; base < m; base += kStage) {
       const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
       // the batch's first entry has its highest list index (the walk runs back to front)

@@ -130,7 +130,7 @@ class DepthPredictorMonocular(nn.Module):
         b, v, r, c = features.shape
         if activated is None:
             activated = torch.relu(features).reshape(b * v * r, c)
-        projected = _RayLinear.apply(activated, linear.weight, linear.bias).view(b, v, r, -1)
+        projected = _RayLinear.apply(activated, linear.weight, linear.bias, None).view(b, v, r, -1)
         uniforms = None
         if not deterministic:
             # discrete_probability_distribution.py:20, same shape and device

@@ -136,7 +136,7 @@ class EncoderEpipolarHead(nn.Module):
             rows_in, context["near"], context["far"], deterministic, gpp,
             self.opacity_exponent(global_step), 1.0 / cfg.gaussians_per_pixel, activated=activated)
         linear = self.to_gaussians[1]
-        head_rows = _RayLinear.apply(activated, linear.weight, linear.bias)
+        head_rows = _RayLinear.apply(activated, linear.weight, linear.bias, None)
         means, cov, harm = _Head.apply(
             cfg.gaussian_adapter, (h, w), srf, eps,
             context["extrinsics"].reshape(b * v, 4, 4).float().contiguous(),

@@ -186,30 +186,35 @@ class EpipolarTransformer(nn.Module):
                 done.record(side)
                 for t in f:
                     t.record_stream(main)
-                folds.append((*f, done))   # fused_layer waits for `done` where it needs f
+                folds.append((*f, done, side))   # fused_layer waits for `done` where it needs f
         return folds
 
     def fused_layer(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None,
                     folded=None, batch=None) -> Tensor:
         """PreNorm(Attention)(x, z=kv) (pre_norm.py:34-35, attention.py:54-70) on the HIP path;
         `attn` is one `layer[0]` of `self.transformer.layers`, fmap is channels-last."""
-        if folded is not None and len(folded) == 4:
+        side = None
+        if folded is not None and len(folded) >= 4:
             torch.cuda.current_stream().wait_event(folded[3])
+            side = folded[4] if len(folded) > 4 else None
             folded = folded[:3]
         return fused_cross_attention(layer_norm(x, attn.norm), fmap, geo, octaves=self._kernel_octaves,
-                                     folded=folded, batch=batch,
+                                     folded=folded, batch=batch, wgrad_stream=side,
                                      **self._layer_weights(attn, view_emb))
 
     def fused_block(self, attn: nn.Module, x: Tensor, fmap: Tensor, geo, view_emb=None,
                     folded=None, batch=None) -> Tensor:
         """`PreNorm(Attention)(x, z=kv) + x` (transformer.py:68): fused_layer plus the residual,
         with the residual's gradient folded into the LayerNorm backward."""
-        if folded is not None and len(folded) == 4:
+        side = None
+        if folded is not None and len(folded) >= 4:
             torch.cuda.current_stream().wait_event(folded[3])
+            side = folded[4] if len(folded) > 4 else None
             folded = folded[:3]
         xn, xr = layer_norm_fork(x, attn.norm)
         return fused_cross_attention(xn, fmap, geo, octaves=self._kernel_octaves, folded=folded,
-                                     batch=batch, **self._layer_weights(attn, view_emb)) + xr
+                                     batch=batch, wgrad_stream=side,
+                                     **self._layer_weights(attn, view_emb)) + xr
 
     def forward(self, features: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor, materialize_sampling: bool = False,

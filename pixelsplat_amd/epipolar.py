@@ -7,6 +7,9 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import os as _os
+from contextlib import nullcontext as _nullcontext
+
 import torch
 from torch import Tensor
 
@@ -119,14 +122,28 @@ def gemm_tn(a: Tensor, b: Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
+# weight gradients of the per-ray GEMMs on the stream the folded weights live on (PS_WGRAD_SIDE=0: on
+# the main stream, as in round 2)
+WGRAD_ON_SIDE_STREAM = _os.environ.get("PS_WGRAD_SIDE", "1") != "0"
+
+
 class _RayLinear(torch.autograd.Function):
     """y = x W^T (+ bias) over all rays; the weight gradient dW = dy^T x is the long-k GEMM
-    hipBLASLt handles badly (gemm_tn.hip)."""
+    hipBLASLt handles badly (gemm_tn.hip).
+
+    `wgrad_stream`: the stream the consumer of dW runs on -- for the folded attention weights the
+    side stream of `EpipolarTransformer.fold_layers` (autograd replays `_FoldWeights.backward` on the
+    stream of its forward).  The split-k GEMM is then launched THERE, behind the main stream's dy:
+    it is an MFMA kernel with nothing downstream on the main stream, so it runs under the VALU-bound
+    kernels that follow (attention backward of the previous layer, the feature-map gradient)
+    instead of between them.  Ordering: same-stream FIFO with its consumer; dy and x are kept alive
+    for the side stream (`record_stream`)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, wgrad_stream=None):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.wgrad_stream = wgrad_stream
         return x @ w.T if bias is None else torch.addmm(bias, x, w.T)
 
     @staticmethod
@@ -138,15 +155,21 @@ class _RayLinear(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0:
-                if want_db:      # the bias gradient falls out of the dY stream of the same kernel
-                    dw, db = gemm_tn(dy, x, colsum=True)
-                else:
-                    dw = gemm_tn(dy, x)
+                side = ctx.wgrad_stream if (WGRAD_ON_SIDE_STREAM and dy.is_cuda) else None
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    dy.record_stream(side)
+                    x.record_stream(side)
+                with torch.cuda.stream(side) if side is not None else _nullcontext():
+                    if want_db:      # the bias gradient falls out of the dY stream of the same kernel
+                        dw, db = gemm_tn(dy, x, colsum=True)
+                    else:
+                        dw = gemm_tn(dy, x)
             else:
                 dw = dy.T @ x
         if want_db and db is None:
             db = dy.sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -218,7 +241,6 @@ def _pad4(n: int) -> int:
 
 # feature-map gradient: two passes (token gradients, then the tile gather) or the single pass
 # that rebuilds every token's gradient per tile; PS_DFMAP_TWO_PASS=0 selects the latter
-import os as _os
 TWO_PASS_FEATURE_GRAD = _os.environ.get("PS_DFMAP_TWO_PASS", "1") != "0"
 
 
@@ -481,7 +503,7 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
                           w_kv: Tensor, w_out: Tensor, b_out: Tensor | None, heads: int,
                           depth_w: Tensor, depth_b: Tensor, octaves: int,
                           view_emb: Tensor | None = None, return_attn: bool = False,
-                          folded=None, batch: FeatureGradBatch | None = None):
+                          folded=None, batch: FeatureGradBatch | None = None, wgrad_stream=None):
     """Attention(x, z=kv) of the reference (attention.py:54-70) for kv = gathered features +
     Linear(PE(relative disparity)) [+ view embedding], without ever forming kv.
 
@@ -490,7 +512,8 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
     view_emb [v-1, c] (already permuted) or None; `folded` = fold_attention_weights(...) of
     the same weights when the caller computed it ahead; `batch` = a FeatureGradBatch shared by
     the chained layers of one forward pass (their feature-map gradients are then scattered
-    together).  Returns [R, 1, d] (and attn [R,H,1,T])."""
+    together); `wgrad_stream` = the stream `folded` was computed on (the weight gradients of the
+    two per-ray GEMMs are launched there, see _RayLinear).  Returns [R, 1, d] (and attn [R,H,1,T])."""
     b, v, h, w, c = fmap_nhwc.shape
     s = geo.xy_sample.shape[-2]
     dh = w_q.shape[0] // heads
@@ -502,11 +525,11 @@ def fused_cross_attention(x: Tensor, fmap_nhwc: Tensor, geo: EpipolarGeometry, *
         folded = fold_attention_weights(w_q=w_q, w_kv=w_kv, w_out=w_out, b_out=b_out, heads=heads,
                                         depth_w=depth_w, depth_b=depth_b, view_emb=view_emb)
     w_in, w_o_t, bias = folded
-    qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None)              # heads x [q~ | u | e]
+    qin = _RayLinear.apply(x.reshape(R, d_in), w_in, None, wgrad_stream)   # heads x [q~ | u | e]
     fused, attn = _FusedEpipolarAttention.apply(
         dims, float(dh) ** -0.5, has_e, fmap_nhwc.reshape(b * v, h, w, c), geo.xy_sample,
         geo.flags, geo.rel_disparity, qin, batch)
-    out = _RayLinear.apply(fused, w_o_t.T, bias).reshape(R, 1, d_out)
+    out = _RayLinear.apply(fused, w_o_t.T, bias, wgrad_stream).reshape(R, 1, d_out)
     if return_attn:
         return out, attn.reshape(R, heads, 1, -1)
     return out
