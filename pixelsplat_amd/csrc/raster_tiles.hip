@@ -187,6 +187,73 @@ __device__ __forceinline__ uint32_t quadrant_mask_part(float gx, float gy, float
 // ------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// One ring entry against quadrant K of the wave, forward.  ONE asm statement holds the quadrant skip
+// (bit K of qm), the shared evaluation of the power and both tails (bit K of `fast`: the short form)
+// behind wave-uniform branches: the compiler sees a single in-place update of the per-pixel registers
+// -- no join of differently allocated values, hence no copies (see the comment at the call site).
+template <int K>
+__device__ __forceinline__ void forward_quadrant(uint32_t qm, uint32_t fast, const float4 q0,
+                                                 const float4 q1, const float4 q2, uint32_t hidx,
+                                                 float px, float py, float alpha_min, float alpha_max,
+                                                 float t_min, float& T, float& C0, float& C1, float& C2,
+                                                 uint32_t& last) {
+  float dx, dy, t, u;
+  asm volatile(
+          "s_bitcmp1_b32 %[qm], %[k]\n"
+          "s_cbranch_scc0 .Lq_end_%=\n"                // the entry cannot reach this quadrant
+          "v_sub_f32 %[dx], %[gx], %[px]\n"
+          "v_sub_f32 %[dy], %[gy], %[py]\n"
+          "v_mul_f32 %[t], %[B], %[dy]\n"
+          "v_mul_f32 %[u], %[C], %[dy]\n"
+          "v_fmac_f32 %[t], %[A], %[dx]\n"             // A dx + B dy
+          "v_mul_f32 %[u], %[u], %[dy]\n"              // C dy^2
+          "v_fmac_f32 %[u], %[dx], %[t]\n"             // power * log2(e)
+          "s_bitcmp1_b32 %[fast], %[k]\n"
+          "s_cbranch_scc0 .Lq_long_%=\n"
+          // ---- short form: power <= 0, alpha < alpha_max (entry_is_plain), nobody can stop
+          "v_exp_f32 %[u], %[u]\n"
+          "s_nop 0\n"                                 // trans -> non-trans VALU use of the result
+          "v_mul_f32 %[u], %[o], %[u]\n"               // alpha
+          "v_cmp_le_f32 vcc, %[amin], %[u]\n"
+          "v_cndmask_b32 %[u], 0, %[u], vcc\n"         // alpha or 0
+          "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
+          "v_mul_f32 %[t], %[T], %[u]\n"               // T alpha
+          "v_sub_f32 %[dx], 1.0, %[u]\n"
+          "v_mul_f32 %[T], %[T], %[dx]\n"              // T (1 - alpha)  (> 0)
+          "s_branch .Lq_acc_%=\n"
+          // ---- long form: T carries the "finished" state in its sign (T > 0: live, T < 0: the
+          // pixel stopped and -T is its final value; pixels outside the image start stopped)
+          ".Lq_long_%=:\n"
+          "v_cmp_ge_f32 s[62:63], 0, %[u]\n"           // power <= 0
+          "v_exp_f32 %[u], %[u]\n"
+          "v_max_f32 %[t], 0, %[T]\n"                  // max(T, 0): 0 for a stopped pixel
+          "v_mul_f32 %[u], %[o], %[u]\n"
+          "v_min_f32 %[u], %[amax], %[u]\n"            // alpha
+          "v_cmp_le_f32 vcc, %[amin], %[u]\n"
+          "s_and_b64 vcc, vcc, s[62:63]\n"             // passes the tests
+          "v_cndmask_b32 %[u], 0, %[u], vcc\n"         // alpha or 0 (0: every update is a no-op)
+          "v_sub_f32 %[dx], 1.0, %[u]\n"
+          "v_mul_f32 %[dx], %[t], %[dx]\n"             // T (1 - alpha)
+          "v_mul_f32 %[t], %[t], %[u]\n"               // T alpha
+          "v_cmp_nlt_f32 s[62:63], %[dx], %[tmin]\n"   // not stopping (a stopped pixel "stops" again)
+          "s_and_b64 vcc, vcc, s[62:63]\n"             // contributes
+          "v_cndmask_b32 %[t], 0, %[t], s[62:63]\n"
+          "v_cndmask_b32 %[T], -|%[T]|, %[dx], s[62:63]\n"
+          "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
+          ".Lq_acc_%=:\n"
+          "v_fmac_f32 %[c0], %[r], %[t]\n"
+          "v_fmac_f32 %[c1], %[g], %[t]\n"
+          "v_fmac_f32 %[c2], %[b], %[t]\n"
+          ".Lq_end_%=:\n"
+      : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [T] "+v"(T), [c0] "+v"(C0),
+        [c1] "+v"(C1), [c2] "+v"(C2), [last] "+v"(last)
+      : [gx] "v"(q0.x), [gy] "v"(q0.y), [A] "v"(q0.z), [B] "v"(q0.w), [C] "v"(q1.x), [o] "v"(q1.y),
+        [r] "v"(q1.z), [g] "v"(q1.w), [b] "v"(q2.x), [hidx] "v"(hidx), [px] "v"(px), [py] "v"(py),
+        [amin] "s"(alpha_min), [amax] "s"(alpha_max), [tmin] "s"(t_min), [qm] "s"(qm),
+        [fast] "s"(fast), [k] "n"(K)
+      : "vcc", "scc", "s62", "s63");
+}
+
 // Inner loop (the result of the round-2 A/B series, profiles/r2_tiles_variants_ab.txt; the superseded
 // variants are in the history before this commit):
 //   * the transmittance carries the "finished" state in its sign (T > 0: live, T < 0: the pixel
@@ -262,88 +329,47 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
   // Stop-free windows.  A pixel can only stop at an entry when T (1 - alpha) < t_min, alpha <= the
   // entry's opacity: with om = the largest opacity among the ring's entries, no pixel with
-  // T >= t_floor = t_min / (1 - om)^8 can stop within the next 8 entries.  Every 8 (kFwdWin) entries ONE compare
-  // per quadrant asks "is every pixel of the wave live with T >= t_floor"; if so, and if the ring holds
-  // plain entries only (entry_is_plain), the window's 8 entries take the short form of the update: no
-  // sign test of the power, no alpha_max clamp, no max(T, 0), no stop test, no selects on the weight and
-  // the transmittance -- 14 full-rate + 3 half-rate + 1 transcendental instruction per quadrant
-  // evaluation instead of 9 + 9 + 1 + 4 packed: ~62 instead of ~84 issue cycles
-  // (profiles/r3_issue_model.txt).  The decision is per window and per wave, not per entry or quadrant:
-  // two forms inside one loop body cost register copies at every join.  84 % of the quadrant
-  // evaluations of BASELINE configs[1] lie in such windows (opacities <= 1/3: t_floor = 2.5e-3).
+  // T >= t_floor = t_min / (1 - om)^8 can stop within the next 8 (kFwdWin) entries.  Every 8 entries ONE
+  // compare per quadrant asks "is every pixel of the quadrant live with T >= t_floor" (bit k of fastq,
+  // wave-uniform); inside such a window a plain entry (entry_is_plain) takes the SHORT form of the
+  // update: no sign test of the power, no alpha_max clamp, no max(T, 0), no stop test, no selects on
+  // the weight and the transmittance -- 14 full-rate + 3 half-rate + 1 transcendental instruction
+  // per quadrant evaluation instead of 9 + 9 + 1 + 4 packed: 64 instead of 94 issue cycles in the same
+  // harness (tools/issue_model.hip `seq` rows, profiles/r3_issue_model.txt).  84 % of the quadrant
+  // evaluations of BASELINE configs[1] qualify (opacities <= 1/3: t_floor = 2.5e-3).
+  // BOTH forms are written out instruction by instruction with every per-pixel value updated in
+  // place: with one form left to the compiler, the two lived in different physical registers and
+  // each switch cost a copy of the whole per-pixel state (measured: +60 M instructions per launch,
+  // 0.89 -> 1.12 ms, profiles/r3_forward_forms_ab.txt).
   float om_run = 0.f, t_floor = __builtin_inff();   // largest opacity in the ring; the windows' floor
-  bool plain_run = true;                             // every entry in the ring is plain
-  auto all_quadrants_stop_free = [&]() {       // every pixel of the wave: live, T >= t_floor
-    bool below = false;
+  uint32_t fastq = 0;                                // bit k: quadrant k is inside a stop-free window
+  auto refresh_fast = [&]() {
+    uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < QW; ++k) below |= Ts[k] < t_floor;     // (Ts < 0: stopped)
-    return !__any(below);
+    for (int k = 0; k < QW; ++k) m |= __any(Ts[k] < t_floor) ? 0u : (1u << k);   // (Ts < 0: stopped)
+    fastq = PS_NO_FAST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(m);   // (wave-uniform: say so)
   };
-  // one ring entry against the (up to QW) quadrants of this wave it can reach; FAST: the short form
-  // (the caller has established a stop-free window and a ring of plain entries)
-  auto process_entry = [&](auto fast_tag, const float4 q0, const float4 q1, const float4 q2) {
-    constexpr bool FAST = decltype(fast_tag)::value;
+  // one ring entry against the (up to QW) quadrants of this wave it can reach
+  auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
     const uint32_t hidx = __float_as_uint(q2.y);
 #if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
 #else
-    // (one quadrant per wave: every ring entry reaches it, no mask to test)
-    const uint32_t qm = QW == 1 ? 1u : __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #endif
-#pragma unroll
-    for (int k = 0; k < QW; ++k) {
-      if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
-        if (FAST) {
-          // The short form, instruction for instruction (left to the compiler the same source
-          // came out with a second compare and register copies around it): 14 full-rate
-          // mul / add / fma class instructions, one v_exp, one compare and two selects; every
-          // per-pixel value is updated in place.
-          float dx, dy, t, u;
-          asm volatile(
-              "v_sub_f32 %[dx], %[gx], %[px]\n"
-              "v_sub_f32 %[dy], %[gy], %[py]\n"
-              "v_mul_f32 %[t], %[B], %[dy]\n"
-              "v_mul_f32 %[u], %[C], %[dy]\n"
-              "v_fmac_f32 %[t], %[A], %[dx]\n"          // A dx + B dy
-              "v_mul_f32 %[u], %[u], %[dy]\n"           // C dy^2
-              "v_fmac_f32 %[u], %[dx], %[t]\n"          // power * log2(e)  (<= 0: entry_is_plain)
-              "v_exp_f32 %[u], %[u]\n"
-              "s_nop 0\n"                              // trans -> non-trans VALU use of the result
-              "v_mul_f32 %[u], %[o], %[u]\n"            // alpha  (< alpha_max: entry_is_plain)
-              "v_cmp_le_f32 vcc, %[amin], %[u]\n"
-              "v_cndmask_b32 %[u], 0, %[u], vcc\n"      // alpha or 0
-              "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
-              "v_mul_f32 %[t], %[T], %[u]\n"            // T alpha
-              "v_sub_f32 %[dx], 1.0, %[u]\n"
-              "v_mul_f32 %[T], %[T], %[dx]\n"           // T (1 - alpha)  (> 0: stop-free window)
-              "v_fmac_f32 %[c0], %[r], %[t]\n"
-              "v_fmac_f32 %[c1], %[g], %[t]\n"
-              "v_fmac_f32 %[c2], %[b], %[t]\n"
-              : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [T] "+v"(Ts[k]),
-                [c0] "+v"(C0[k]), [c1] "+v"(C1[k]), [c2] "+v"(C2[k]), [last] "+v"(last[k])
-              : [gx] "v"(q0.x), [gy] "v"(q0.y), [A] "v"(q0.z), [B] "v"(q0.w), [C] "v"(q1.x),
-                [o] "v"(q1.y), [r] "v"(q1.z), [g] "v"(q1.w), [b] "v"(q2.x), [hidx] "v"(hidx),
-                [px] "v"(pxf[k]), [py] "v"(pyf[k]), [amin] "s"(alpha_min)
-              : "vcc");
-        } else {
-          const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
-          const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
-          const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
-          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
-          const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
-          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-          float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
-          asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
-          const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
-          const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
-          const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
-          Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
-          C0[k] = fmaf(q1.z, wgt, C0[k]);
-          C1[k] = fmaf(q1.w, wgt, C1[k]);
-          C2[k] = fmaf(q2.x, wgt, C2[k]);
-          last[k] = (ok & !stop) ? hidx : last[k];
-        }
-      }
+    const uint32_t fast = (uint32_t)__builtin_amdgcn_readfirstlane((qm & kPlainBit) ? fastq : 0u);
+    // (forward_quadrant: ONE asm statement per quadrant with the quadrant skip, the shared evaluation of
+    // the power and both tails behind wave-uniform branches)
+    forward_quadrant<0>(qm, fast, q0, q1, q2, hidx, pxf[0], pyf[0], alpha_min, alpha_max, t_min, Ts[0],
+                        C0[0], C1[0], C2[0], last[0]);
+    if constexpr (QW > 1)
+      forward_quadrant<1>(qm, fast, q0, q1, q2, hidx, pxf[1], pyf[1], alpha_min, alpha_max, t_min, Ts[1],
+                          C0[1], C1[1], C2[1], last[1]);
+    if constexpr (QW > 2) {
+      forward_quadrant<2>(qm, fast, q0, q1, q2, hidx, pxf[2], pyf[2], alpha_min, alpha_max, t_min, Ts[2],
+                          C0[2], C1[2], C2[2], last[2]);
+      forward_quadrant<3>(qm, fast, q0, q1, q2, hidx, pxf[3], pyf[3], alpha_min, alpha_max, t_min, Ts[3],
+                          C0[3], C1[3], C2[3], last[3]);
     }
   };
   auto every_pixel_stopped = [&]() {
@@ -352,33 +378,21 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     for (int k = 0; k < QW; ++k) any |= Ts[k] > 0.f;
     return !__any(any);
   };
-  // 8 ring entries (one window) from entry j0 of the current blend call, two per trip, each one's
-  // record read from LDS while the other is blended; a0..a2 hold entry j0's record on entry and
-  // entry jend's on return
-  float4 a0, a1, a2;
-  auto window = [&](auto fast_tag, uint32_t j0, uint32_t jend) {
-    for (uint32_t j = j0; j < jend; j += 2) {
-      uint32_t slot = (b_head + j + 1) & (kQB - 1);       // (stale beyond the call's m: never processed)
+  auto blend1 = [&](uint32_t m) {
+    uint32_t slot = b_head & (kQB - 1);
+    float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
+    refresh_fast();                                  // the first window of this call
+    for (uint32_t j = 0; j < m; j += 2) {
+      slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
       const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-      process_entry(fast_tag, a0, a1, a2);
-      if (j + 1 >= jend) break;
+      process_entry(a0, a1, a2);
+      if (j + 1 >= m) break;
       slot = (b_head + j + 2) & (kQB - 1);
       a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-      process_entry(fast_tag, b0, b1, b2);
-    }
-  };
-  auto blend1 = [&](uint32_t m) {
-    const uint32_t slot = b_head & (kQB - 1);
-    a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-    const bool ring_plain = plain_run && !PS_NO_FAST;
-    for (uint32_t j0 = 0; j0 < m; j0 += kFwdWin) {
-      const uint32_t jend = j0 + kFwdWin < m ? j0 + kFwdWin : m;
-      // ONE compare per quadrant decides the form of the next 8 entries (see above)
-      if (ring_plain && all_quadrants_stop_free()) {
-        window(std::true_type{}, j0, jend);
-      } else {
-        window(std::false_type{}, j0, jend);
-        if (every_pixel_stopped()) { all_done = true; break; }
+      process_entry(b0, b1, b2);
+      if ((j & (uint32_t)(kFwdWin - 1)) == (uint32_t)(kFwdWin - 2)) {   // next window; termination
+        refresh_fast();
+        if (fastq == 0u && every_pixel_stopped()) { all_done = true; break; }
       }
     }
     b_head += m;
@@ -406,7 +420,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
         gather(id2, n0, n1, n2);
         id2 = idx_of(first + 2 * kBatch);
       }
-      bool keep = false, not_plain = false;
+      bool keep = false;
       float op_keep = 0.f;
       float4 q0, q1, q2;
       if ((uint32_t)lane < m) {
@@ -415,10 +429,10 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                                     : quadrant_mask_part<QW>(r0.x, r0.y, A, B, Cq, r1.y, alpha_min,
                                                              x0, y0, q_first);
         keep = qm != 0u;
-        not_plain = keep && !entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max);
+        const uint32_t plain = entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max) ? kPlainBit : 0u;
         q0 = make_float4(r0.x, r0.y, A, B);
         q1 = make_float4(Cq, r1.y, r2.x, r2.y);
-        q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
+        q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm | plain), 0.f);
         op_keep = keep ? r1.y : 0.f;
       }
       const uint64_t mask = __ballot(keep);
@@ -428,10 +442,9 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       }
       const bool ring_was_empty = b_tail == b_head;
       b_tail += (uint32_t)__popcll(mask);
-      // largest opacity / "all plain" over the entries the ring holds: running values, reset when
-      // the ring runs empty (leftovers can outlive several refine batches that kept nothing)
-      if (ring_was_empty) { om_run = 0.f; plain_run = true; }
-      plain_run = plain_run && !__any(not_plain);
+      // largest opacity over the entries the ring holds: a running value, reset when the ring runs
+      // empty (leftovers can outlive several refine batches that kept nothing)
+      if (ring_was_empty) om_run = 0.f;
       om_run = fmaxf(om_run, __uint_as_float(wave_max_u(__float_as_uint(op_keep))));   // (>= 0: bits order)
       {
         const float om = fminf(om_run, alpha_max);

@@ -134,8 +134,150 @@ __global__ void __launch_bounds__(256) blk(float* out, uint64_t* ticks, int iter
   if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
 }
 
-static float* g_out; static uint64_t* g_ticks;
 
+
+static float* g_out; static uint64_t* g_ticks;
+// The per-quadrant blocks as they sit in the kernel: one quadrant after the other behind wave-uniform
+// branches (no interleaving across quadrants), entry values in registers.
+//   MODE 0: the long form as the compiler emits it (packed pairs + selects)
+//   MODE 1: the short form, hand-written VOP2 sequence (raster_tiles.hip, round 3)
+//   MODE 2: the short form left to the compiler (packed pairs where it wants them)
+//   MODE 3: the hand-written short form with two quadrants interleaved instruction by instruction
+template <int MODE>
+__global__ void __launch_bounds__(256) seq(float* out, uint64_t* ticks, int iters, uint32_t qmask) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  float pxf[4], pyf[4], Ts[4], C0[4], C1[4], C2[4]; uint32_t last[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    pxf[q] = (float)(lane & 7) + 8.f * (q & 1); pyf[q] = (float)(lane >> 3) + 8.f * (q >> 1);
+    Ts[q] = 1.f; C0[q] = C1[q] = C2[q] = 0.f; last[q] = 0;
+  }
+  float gx = 7.5f + 0.01f * blockIdx.x, gy = 8.5f, A = -0.02f, B = 0.001f, Cq = -0.03f, o = 0.3f;
+  float c0 = 0.5f, c1 = 0.25f, c2 = 0.125f;
+  const float amax = 0.99f, amin = 1.f / 255.f, tmin = 1e-4f;
+  const uint32_t qm = __builtin_amdgcn_readfirstlane(qmask);
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t hidx = (uint32_t)it + 1u;
+    gx += 1e-4f;
+    if (MODE == 3) {
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        if (qm & (1u << q)) {
+          float dx, dy, t, u, dx2, dy2, t2, u2;
+          asm volatile(
+              "v_sub_f32 %[dx], %[gx], %[px]\n v_sub_f32 %[dx2], %[gx], %[px2]\n"
+              "v_sub_f32 %[dy], %[gy], %[py]\n v_sub_f32 %[dy2], %[gy], %[py2]\n"
+              "v_mul_f32 %[t], %[B], %[dy]\n v_mul_f32 %[t2], %[B], %[dy2]\n"
+              "v_mul_f32 %[u], %[C], %[dy]\n v_mul_f32 %[u2], %[C], %[dy2]\n"
+              "v_fmac_f32 %[t], %[A], %[dx]\n v_fmac_f32 %[t2], %[A], %[dx2]\n"
+              "v_mul_f32 %[u], %[u], %[dy]\n v_mul_f32 %[u2], %[u2], %[dy2]\n"
+              "v_fmac_f32 %[u], %[dx], %[t]\n v_fmac_f32 %[u2], %[dx2], %[t2]\n"
+              "v_exp_f32 %[u], %[u]\n v_exp_f32 %[u2], %[u2]\n"
+              "v_mul_f32 %[u], %[o], %[u]\n v_mul_f32 %[u2], %[o], %[u2]\n"
+              "v_cmp_le_f32 vcc, %[amin], %[u]\n v_cmp_le_f32 s[10:11], %[amin], %[u2]\n"
+              "v_cndmask_b32 %[u], 0, %[u], vcc\n v_cndmask_b32 %[u2], 0, %[u2], s[10:11]\n"
+              "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n v_cndmask_b32 %[last2], %[last2], %[hidx], s[10:11]\n"
+              "v_mul_f32 %[t], %[T], %[u]\n v_mul_f32 %[t2], %[T2], %[u2]\n"
+              "v_sub_f32 %[dx], 1.0, %[u]\n v_sub_f32 %[dx2], 1.0, %[u2]\n"
+              "v_mul_f32 %[T], %[T], %[dx]\n v_mul_f32 %[T2], %[T2], %[dx2]\n"
+              "v_fmac_f32 %[c0], %[r], %[t]\n v_fmac_f32 %[c02], %[r], %[t2]\n"
+              "v_fmac_f32 %[c1], %[g], %[t]\n v_fmac_f32 %[c12], %[g], %[t2]\n"
+              "v_fmac_f32 %[c2], %[b], %[t]\n v_fmac_f32 %[c22], %[b], %[t2]\n"
+              : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [T] "+v"(Ts[q]),
+                [c0] "+v"(C0[q]), [c1] "+v"(C1[q]), [c2] "+v"(C2[q]), [last] "+v"(last[q]),
+                [dx2] "=&v"(dx2), [dy2] "=&v"(dy2), [t2] "=&v"(t2), [u2] "=&v"(u2), [T2] "+v"(Ts[q + 1]),
+                [c02] "+v"(C0[q + 1]), [c12] "+v"(C1[q + 1]), [c22] "+v"(C2[q + 1]), [last2] "+v"(last[q + 1])
+              : [gx] "v"(gx), [gy] "v"(gy), [A] "v"(A), [B] "v"(B), [C] "v"(Cq), [o] "v"(o), [r] "v"(c0),
+                [g] "v"(c1), [b] "v"(c2), [hidx] "v"(hidx), [px] "v"(pxf[q]), [py] "v"(pyf[q]),
+                [px2] "v"(pxf[q + 1]), [py2] "v"(pyf[q + 1]), [amin] "s"(amin)
+              : "vcc", "s10", "s11");
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (qm & (1u << q)) {
+        if (MODE == 1) {
+          float dx, dy, t, u;
+          asm volatile(
+              "v_sub_f32 %[dx], %[gx], %[px]\n"
+              "v_sub_f32 %[dy], %[gy], %[py]\n"
+              "v_mul_f32 %[t], %[B], %[dy]\n"
+              "v_mul_f32 %[u], %[C], %[dy]\n"
+              "v_fmac_f32 %[t], %[A], %[dx]\n"
+              "v_mul_f32 %[u], %[u], %[dy]\n"
+              "v_fmac_f32 %[u], %[dx], %[t]\n"
+              "v_exp_f32 %[u], %[u]\n"
+              "s_nop 0\n"
+              "v_mul_f32 %[u], %[o], %[u]\n"
+              "v_cmp_le_f32 vcc, %[amin], %[u]\n"
+              "v_cndmask_b32 %[u], 0, %[u], vcc\n"
+              "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
+              "v_mul_f32 %[t], %[T], %[u]\n"
+              "v_sub_f32 %[dx], 1.0, %[u]\n"
+              "v_mul_f32 %[T], %[T], %[dx]\n"
+              "v_fmac_f32 %[c0], %[r], %[t]\n"
+              "v_fmac_f32 %[c1], %[g], %[t]\n"
+              "v_fmac_f32 %[c2], %[b], %[t]\n"
+              : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [T] "+v"(Ts[q]),
+                [c0] "+v"(C0[q]), [c1] "+v"(C1[q]), [c2] "+v"(C2[q]), [last] "+v"(last[q])
+              : [gx] "v"(gx), [gy] "v"(gy), [A] "v"(A), [B] "v"(B), [C] "v"(Cq), [o] "v"(o), [r] "v"(c0),
+                [g] "v"(c1), [b] "v"(c2), [hidx] "v"(hidx), [px] "v"(pxf[q]), [py] "v"(pyf[q]),
+                [amin] "s"(amin)
+              : "vcc");
+        } else {
+          const f2 dd = f2{gx, gy} - f2{pxf[q], pyf[q]};
+          const f2 bc = f2{B, Cq} * f2{dd.y, dd.y};
+          const float pw = fmaf(dd.x, fmaf(A, dd.x, bc.x), dd.y * bc.y);
+          if (MODE == 2) {
+            const float alpha = o * __builtin_amdgcn_exp2f(pw);
+            const bool ok = alpha >= amin;
+            const float ale = ok ? alpha : 0.f;
+            const f2 tw = f2{Ts[q], Ts[q]} * f2{1.f - ale, ale};
+            Ts[q] = tw.x;
+            C0[q] = fmaf(c0, tw.y, C0[q]); C1[q] = fmaf(c1, tw.y, C1[q]); C2[q] = fmaf(c2, tw.y, C2[q]);
+            last[q] = ok ? hidx : last[q];
+          } else {
+            const float alpha = fminf(amax, o * __builtin_amdgcn_exp2f(pw));
+            const bool ok = (pw <= 0.f) & (alpha >= amin);
+            const float ale = ok ? alpha : 0.f;
+            float Tp;
+            asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[q]));
+            const f2 tw = f2{Tp, Tp} * f2{1.f - ale, ale};
+            const bool stop = tw.x < tmin;
+            const float wgt = stop ? 0.f : tw.y;
+            Ts[q] = stop ? -fabsf(Ts[q]) : tw.x;
+            C0[q] = fmaf(c0, wgt, C0[q]); C1[q] = fmaf(c1, wgt, C1[q]); C2[q] = fmaf(c2, wgt, C2[q]);
+            last[q] = (ok & !stop) ? hidx : last[q];
+          }
+        }
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s += Ts[q] + C0[q] + C1[q] + C2[q] + (float)last[q];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+template <typename K>
+void timeit_q(const char* name, K kern, int w, int iters, uint32_t qmask, double evals_per_iter) {
+  const int blocks = 256 * w;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, g_out, g_ticks, iters, qmask);
+  hipEventRecord(a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, g_out, g_ticks, iters, qmask);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double evals_per_simd = (double)iters * evals_per_iter * w;
+  printf("%-52s w=%d qmask=%x  %8.3f ms  %.1f cyc per quadrant evaluation @2.4GHz\n", name, w, qmask, ms,
+         2400.0 * ms * 1e3 / evals_per_simd);
+}
 template <typename K>
 void timeit(const char* name, K kern, int w, double inst_per_iter, int iters) {
   const int blocks = 256 * w;
@@ -166,5 +308,13 @@ int main() {
   RUN(20, "v_fmac_e32 + v_mul_e32 pair", 2);
   for (int w : {1, 2, 4, 8}) timeit("forward block x4 quadrants / trip", blk<0>, w, 4.0, 20000);
   for (int w : {1, 2, 4}) timeit("backward block x4 quadrants / trip", blk<1>, w, 4.0, 20000);
+  for (int w : {1, 4, 8})
+    for (uint32_t qmask : {0xFu, 0x5u, 0x1u}) {
+      const double ev = __builtin_popcount(qmask);
+      timeit_q("seq long form (compiler)", seq<0>, w, 20000, qmask, ev);
+      timeit_q("seq short form (hand-written VOP2)", seq<1>, w, 20000, qmask, ev);
+      timeit_q("seq short form (compiler)", seq<2>, w, 20000, qmask, ev);
+      if (qmask != 0x1u) timeit_q("seq short form, two quadrants interleaved", seq<3>, w, 20000, qmask == 0xFu ? 0x5u : 0x1u, qmask == 0xFu ? 4.0 : 2.0);
+    }
   return 0;
 }
