@@ -185,73 +185,72 @@ __device__ __forceinline__ uint32_t quadrant_mask_part(float gx, float gy, float
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One ring entry against quadrant K of the wave, forward.  ONE asm statement holds the quadrant skip
 // (bit K of qm), the shared evaluation of the power and both tails (bit K of `fast`: the short form)
 // behind wave-uniform branches: the compiler sees a single in-place update of the per-pixel registers
 // -- no join of differently allocated values, hence no copies (see the comment at the call site).
+// The instruction selection is the one that measured best in the kernel (profiles/r3_forward_forms_ab.txt):
+// packed pairs for (dx, dy), (B dy, C dy), (T (1 - a), T a) and the colour pair -- in this kernel the
+// time follows the instruction COUNT, a packed instruction counts once -- v122..v127 are the
+// temporaries: v[124:125] = (dx, dy) then (T (1 - a) | 1 - a, T a | a), v[126:127] = (B dy, C dy) then
+// (max(T, 0), -), v123 = power, v122 = exp / alpha.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int K>
-__device__ __forceinline__ void forward_quadrant(uint32_t qm, uint32_t fast, const float4 q0,
-                                                 const float4 q1, const float4 q2, uint32_t hidx,
-                                                 float px, float py, float alpha_min, float alpha_max,
-                                                 float t_min, float& T, float& C0, float& C1, float& C2,
-                                                 uint32_t& last) {
-  float dx, dy, t, u;
+__device__ __forceinline__ void forward_quadrant(uint32_t qm, uint32_t fast, f32x2 G, float A, f32x2 BC,
+                                                 float o, f32x2 c01, float c2, uint32_t hidx, f32x2 P,
+                                                 float alpha_min, float alpha_max, float t_min,
+                                                 float& T, f32x2& C01, float& C2, uint32_t& last) {
   asm volatile(
-          "s_bitcmp1_b32 %[qm], %[k]\n"
-          "s_cbranch_scc0 .Lq_end_%=\n"                // the entry cannot reach this quadrant
-          "v_sub_f32 %[dx], %[gx], %[px]\n"
-          "v_sub_f32 %[dy], %[gy], %[py]\n"
-          "v_mul_f32 %[t], %[B], %[dy]\n"
-          "v_mul_f32 %[u], %[C], %[dy]\n"
-          "v_fmac_f32 %[t], %[A], %[dx]\n"             // A dx + B dy
-          "v_mul_f32 %[u], %[u], %[dy]\n"              // C dy^2
-          "v_fmac_f32 %[u], %[dx], %[t]\n"             // power * log2(e)
-          "s_bitcmp1_b32 %[fast], %[k]\n"
-          "s_cbranch_scc0 .Lq_long_%=\n"
-          // ---- short form: power <= 0, alpha < alpha_max (entry_is_plain), nobody can stop
-          "v_exp_f32 %[u], %[u]\n"
-          "s_nop 0\n"                                 // trans -> non-trans VALU use of the result
-          "v_mul_f32 %[u], %[o], %[u]\n"               // alpha
-          "v_cmp_le_f32 vcc, %[amin], %[u]\n"
-          "v_cndmask_b32 %[u], 0, %[u], vcc\n"         // alpha or 0
-          "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
-          "v_mul_f32 %[t], %[T], %[u]\n"               // T alpha
-          "v_sub_f32 %[dx], 1.0, %[u]\n"
-          "v_mul_f32 %[T], %[T], %[dx]\n"              // T (1 - alpha)  (> 0)
-          "s_branch .Lq_acc_%=\n"
-          // ---- long form: T carries the "finished" state in its sign (T > 0: live, T < 0: the
-          // pixel stopped and -T is its final value; pixels outside the image start stopped)
-          ".Lq_long_%=:\n"
-          "v_cmp_ge_f32 s[62:63], 0, %[u]\n"           // power <= 0
-          "v_exp_f32 %[u], %[u]\n"
-          "v_max_f32 %[t], 0, %[T]\n"                  // max(T, 0): 0 for a stopped pixel
-          "v_mul_f32 %[u], %[o], %[u]\n"
-          "v_min_f32 %[u], %[amax], %[u]\n"            // alpha
-          "v_cmp_le_f32 vcc, %[amin], %[u]\n"
-          "s_and_b64 vcc, vcc, s[62:63]\n"             // passes the tests
-          "v_cndmask_b32 %[u], 0, %[u], vcc\n"         // alpha or 0 (0: every update is a no-op)
-          "v_sub_f32 %[dx], 1.0, %[u]\n"
-          "v_mul_f32 %[dx], %[t], %[dx]\n"             // T (1 - alpha)
-          "v_mul_f32 %[t], %[t], %[u]\n"               // T alpha
-          "v_cmp_nlt_f32 s[62:63], %[dx], %[tmin]\n"   // not stopping (a stopped pixel "stops" again)
-          "s_and_b64 vcc, vcc, s[62:63]\n"             // contributes
-          "v_cndmask_b32 %[t], 0, %[t], s[62:63]\n"
-          "v_cndmask_b32 %[T], -|%[T]|, %[dx], s[62:63]\n"
-          "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
-          ".Lq_acc_%=:\n"
-          "v_fmac_f32 %[c0], %[r], %[t]\n"
-          "v_fmac_f32 %[c1], %[g], %[t]\n"
-          "v_fmac_f32 %[c2], %[b], %[t]\n"
-          ".Lq_end_%=:\n"
-      : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [T] "+v"(T), [c0] "+v"(C0),
-        [c1] "+v"(C1), [c2] "+v"(C2), [last] "+v"(last)
-      : [gx] "v"(q0.x), [gy] "v"(q0.y), [A] "v"(q0.z), [B] "v"(q0.w), [C] "v"(q1.x), [o] "v"(q1.y),
-        [r] "v"(q1.z), [g] "v"(q1.w), [b] "v"(q2.x), [hidx] "v"(hidx), [px] "v"(px), [py] "v"(py),
-        [amin] "s"(alpha_min), [amax] "s"(alpha_max), [tmin] "s"(t_min), [qm] "s"(qm),
-        [fast] "s"(fast), [k] "n"(K)
-      : "vcc", "scc", "s62", "s63");
+      "s_bitcmp1_b32 %[qm], %[k]\n"
+      "s_cbranch_scc0 .Lq_end_%=\n"                // the entry cannot reach this quadrant
+      "v_pk_add_f32 v[124:125], %[G], %[P] neg_lo:[0,1] neg_hi:[0,1]\n"   // (dx, dy)
+      "s_nop 0\n"
+      "v_pk_mul_f32 v[126:127], %[BC], v[124:125] op_sel:[0,1]\n"         // (B dy, C dy)
+      "s_nop 0\n"
+      "v_mul_f32 v123, v125, v127\n"               // C dy^2
+      "v_fmac_f32 v126, %[A], v124\n"              // A dx + B dy
+      "v_fmac_f32 v123, v124, v126\n"              // power * log2(e)
+      "s_bitcmp1_b32 %[fast], %[k]\n"
+      "v_exp_f32 v122, v123\n"
+      "s_cbranch_scc0 .Lq_long_%=\n"
+      // ---- short form: power <= 0, alpha < alpha_max (entry_is_plain), nobody can stop
+      "s_nop 0\n"                                 // trans -> non-trans VALU use of the result
+      "v_mul_f32 v122, %[o], v122\n"               // alpha
+      "v_cmp_le_f32 vcc, %[amin], v122\n"
+      "v_cndmask_b32 v125, 0, v122, vcc\n"         // alpha or 0
+      "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
+      "v_sub_f32 v124, 1.0, v125\n"
+      "v_mul_f32 v125, %[T], v125\n"               // T alpha
+      "v_mul_f32 %[T], %[T], v124\n"               // T (1 - alpha)  (> 0)
+      "s_branch .Lq_acc_%=\n"
+      // ---- long form: T carries the "finished" state in its sign (T > 0: live, T < 0: the pixel
+      // stopped and -T is its final value; pixels outside the image start stopped)
+      ".Lq_long_%=:\n"
+      "v_cmp_ge_f32 vcc, 0, v123\n"                // power <= 0
+      "v_max_f32 v126, 0, %[T]\n"                  // max(T, 0): 0 for a stopped pixel
+      "v_mul_f32 v122, %[o], v122\n"
+      "v_min_f32 v122, %[amax], v122\n"            // alpha
+      "v_cmp_le_f32 s[62:63], %[amin], v122\n"
+      "s_and_b64 vcc, vcc, s[62:63]\n"             // passes the tests
+      "v_cndmask_b32 v125, 0, v122, vcc\n"         // alpha or 0 (0: every update is a no-op)
+      "v_sub_f32 v124, 1.0, v125\n"
+      "v_pk_mul_f32 v[124:125], v[126:127], v[124:125] op_sel_hi:[0,1]\n"   // (T (1 - a), T a)
+      "s_nop 0\n"
+      "v_cmp_ngt_f32 s[62:63], %[tmin], v124\n"    // not stopping (a stopped pixel "stops" again)
+      "s_and_b64 vcc, vcc, s[62:63]\n"             // contributes
+      "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
+      "v_cndmask_b32 v125, 0, v125, s[62:63]\n"
+      "v_cndmask_b32 %[T], -|%[T]|, v124, s[62:63]\n"
+      ".Lq_acc_%=:\n"
+      "v_pk_fma_f32 %[C01], %[c01], v[124:125], %[C01] op_sel:[0,1,0]\n"
+      "v_fmac_f32 %[C2], %[c2], v125\n"
+      ".Lq_end_%=:\n"
+      : [T] "+v"(T), [C01] "+v"(C01), [C2] "+v"(C2), [last] "+v"(last)
+      : [G] "v"(G), [A] "v"(A), [BC] "v"(BC), [o] "v"(o), [c01] "v"(c01), [c2] "v"(c2),
+        [hidx] "v"(hidx), [P] "v"(P), [amin] "s"(alpha_min), [amax] "s"(alpha_max), [tmin] "s"(t_min),
+        [qm] "s"(qm), [fast] "s"(fast), [k] "n"(K)
+      : "vcc", "scc", "s62", "s63", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
 // Inner loop (the result of the round-2 A/B series, profiles/r2_tiles_variants_ab.txt; the superseded
@@ -304,18 +303,18 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const uint32_t* list = point_list + l_start;
 
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  int px[QW], py[QW]; float pxf[QW], pyf[QW]; bool live[QW];
-  float T[QW], C0[QW], C1[QW], C2[QW]; uint32_t last[QW];
+  int px[QW], py[QW]; f32x2 pxy[QW]; bool live[QW];     // pxy: the pixel centre as a register pair
+  float T[QW], C2[QW]; f32x2 C01[QW]; uint32_t last[QW];   // C01: colour channels 0, 1 as a pair
   bool any_live = false;
 #pragma unroll
   for (int k = 0; k < QW; ++k) {
     const int q = q_first + k;
     px[k] = tx * kTile + 8 * (q & 1) + (lane & 7);
     py[k] = ty * kTile + 8 * (q >> 1) + (lane >> 3);
-    pxf[k] = (float)px[k]; pyf[k] = (float)py[k];
+    pxy[k] = f32x2{(float)px[k], (float)py[k]};
     live[k] = px[k] < W && py[k] < H;
     any_live |= live[k];
-    T[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f; last[k] = 0;
+    T[k] = 1.f; C01[k] = f32x2{0.f, 0.f}; C2[k] = 0.f; last[k] = 0;
   }
   uint32_t b_head = 0, b_tail = 0;  // wave-uniform ring cursors
   const uint64_t lt = lanemask_lt();
@@ -360,16 +359,17 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     const uint32_t fast = (uint32_t)__builtin_amdgcn_readfirstlane((qm & kPlainBit) ? fastq : 0u);
     // (forward_quadrant: ONE asm statement per quadrant with the quadrant skip, the shared evaluation of
     // the power and both tails behind wave-uniform branches)
-    forward_quadrant<0>(qm, fast, q0, q1, q2, hidx, pxf[0], pyf[0], alpha_min, alpha_max, t_min, Ts[0],
-                        C0[0], C1[0], C2[0], last[0]);
+    const f32x2 G = f32x2{q0.x, q0.y}, BC = f32x2{q0.w, q1.x}, c01 = f32x2{q1.z, q1.w};
+    forward_quadrant<0>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[0], alpha_min, alpha_max, t_min,
+                        Ts[0], C01[0], C2[0], last[0]);
     if constexpr (QW > 1)
-      forward_quadrant<1>(qm, fast, q0, q1, q2, hidx, pxf[1], pyf[1], alpha_min, alpha_max, t_min, Ts[1],
-                          C0[1], C1[1], C2[1], last[1]);
+      forward_quadrant<1>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[1], alpha_min, alpha_max,
+                          t_min, Ts[1], C01[1], C2[1], last[1]);
     if constexpr (QW > 2) {
-      forward_quadrant<2>(qm, fast, q0, q1, q2, hidx, pxf[2], pyf[2], alpha_min, alpha_max, t_min, Ts[2],
-                          C0[2], C1[2], C2[2], last[2]);
-      forward_quadrant<3>(qm, fast, q0, q1, q2, hidx, pxf[3], pyf[3], alpha_min, alpha_max, t_min, Ts[3],
-                          C0[3], C1[3], C2[3], last[3]);
+      forward_quadrant<2>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[2], alpha_min, alpha_max,
+                          t_min, Ts[2], C01[2], C2[2], last[2]);
+      forward_quadrant<3>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[3], alpha_min, alpha_max,
+                          t_min, Ts[3], C01[3], C2[3], last[3]);
     }
   };
   auto every_pixel_stopped = [&]() {
@@ -475,8 +475,8 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     if (px[k] < W && py[k] < H) {
       const size_t pix = (size_t)py[k] * W + px[k];
       float* oc = out_color + (size_t)v * 3 * P;
-      oc[pix] = C0[k] + T[k] * bg0;
-      oc[P + pix] = C1[k] + T[k] * bg1;
+      oc[pix] = C01[k].x + T[k] * bg0;
+      oc[P + pix] = C01[k].y + T[k] * bg1;
       oc[2 * P + pix] = C2[k] + T[k] * bg2;
       final_T[(size_t)v * P + pix] = T[k];
       n_contrib[(size_t)v * P + pix] = last[k];
