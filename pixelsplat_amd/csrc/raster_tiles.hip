@@ -40,10 +40,6 @@ namespace ps {
 #ifndef PS_NO_FAST
 #define PS_NO_FAST 0        // 1: never take the short forms (A/B of what they buy)
 #endif
-#ifndef PS_FWD_WINDOW
-#define PS_FWD_WINDOW 8     // entries per stop-free window of the forward (even)
-#endif
-constexpr int kFwdWin = PS_FWD_WINDOW;
 constexpr int kFwdQW = PS_FWD_QW;
 constexpr int kFwdParts = 4 / kFwdQW;
 static_assert(kFwdQW == 1 || kFwdQW == 2 || kFwdQW == 4, "PS_FWD_QW must be 1, 2 or 4");
@@ -186,72 +182,7 @@ __device__ __forceinline__ uint32_t quadrant_mask_part(float gx, float gy, float
 // forward
 // ------------------------------------------------------------------------------------
 
-// One ring entry against quadrant K of the wave, forward.  ONE asm statement holds the quadrant skip
-// (bit K of qm), the shared evaluation of the power and both tails (bit K of `fast`: the short form)
-// behind wave-uniform branches: the compiler sees a single in-place update of the per-pixel registers
-// -- no join of differently allocated values, hence no copies (see the comment at the call site).
-// The instruction selection is the one that measured best in the kernel (profiles/r3_forward_forms_ab.txt):
-// packed pairs for (dx, dy), (B dy, C dy), (T (1 - a), T a) and the colour pair -- in this kernel the
-// time follows the instruction COUNT, a packed instruction counts once -- v122..v127 are the
-// temporaries: v[124:125] = (dx, dy) then (T (1 - a) | 1 - a, T a | a), v[126:127] = (B dy, C dy) then
-// (max(T, 0), -), v123 = power, v122 = exp / alpha.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int K>
-__device__ __forceinline__ void forward_quadrant(uint32_t qm, uint32_t fast, f32x2 G, float A, f32x2 BC,
-                                                 float o, f32x2 c01, float c2, uint32_t hidx, f32x2 P,
-                                                 float alpha_min, float alpha_max, float t_min,
-                                                 float& T, f32x2& C01, float& C2, uint32_t& last) {
-  asm volatile(
-      "s_bitcmp1_b32 %[qm], %[k]\n"
-      "s_cbranch_scc0 .Lq_end_%=\n"                // the entry cannot reach this quadrant
-      "v_pk_add_f32 v[124:125], %[G], %[P] neg_lo:[0,1] neg_hi:[0,1]\n"   // (dx, dy)
-      "s_nop 0\n"
-      "v_pk_mul_f32 v[126:127], %[BC], v[124:125] op_sel:[0,1]\n"         // (B dy, C dy)
-      "s_nop 0\n"
-      "v_mul_f32 v123, v125, v127\n"               // C dy^2
-      "v_fmac_f32 v126, %[A], v124\n"              // A dx + B dy
-      "v_fmac_f32 v123, v124, v126\n"              // power * log2(e)
-      "s_bitcmp1_b32 %[fast], %[k]\n"
-      "v_exp_f32 v122, v123\n"
-      "s_cbranch_scc0 .Lq_long_%=\n"
-      // ---- short form: power <= 0, alpha < alpha_max (entry_is_plain), nobody can stop
-      "s_nop 0\n"                                 // trans -> non-trans VALU use of the result
-      "v_mul_f32 v122, %[o], v122\n"               // alpha
-      "v_cmp_le_f32 vcc, %[amin], v122\n"
-      "v_cndmask_b32 v125, 0, v122, vcc\n"         // alpha or 0
-      "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
-      "v_sub_f32 v124, 1.0, v125\n"
-      "v_mul_f32 v125, %[T], v125\n"               // T alpha
-      "v_mul_f32 %[T], %[T], v124\n"               // T (1 - alpha)  (> 0)
-      "s_branch .Lq_acc_%=\n"
-      // ---- long form: T carries the "finished" state in its sign (T > 0: live, T < 0: the pixel
-      // stopped and -T is its final value; pixels outside the image start stopped)
-      ".Lq_long_%=:\n"
-      "v_cmp_ge_f32 vcc, 0, v123\n"                // power <= 0
-      "v_max_f32 v126, 0, %[T]\n"                  // max(T, 0): 0 for a stopped pixel
-      "v_mul_f32 v122, %[o], v122\n"
-      "v_min_f32 v122, %[amax], v122\n"            // alpha
-      "v_cmp_le_f32 s[62:63], %[amin], v122\n"
-      "s_and_b64 vcc, vcc, s[62:63]\n"             // passes the tests
-      "v_cndmask_b32 v125, 0, v122, vcc\n"         // alpha or 0 (0: every update is a no-op)
-      "v_sub_f32 v124, 1.0, v125\n"
-      "v_pk_mul_f32 v[124:125], v[126:127], v[124:125] op_sel_hi:[0,1]\n"   // (T (1 - a), T a)
-      "s_nop 0\n"
-      "v_cmp_ngt_f32 s[62:63], %[tmin], v124\n"    // not stopping (a stopped pixel "stops" again)
-      "s_and_b64 vcc, vcc, s[62:63]\n"             // contributes
-      "v_cndmask_b32 %[last], %[last], %[hidx], vcc\n"
-      "v_cndmask_b32 v125, 0, v125, s[62:63]\n"
-      "v_cndmask_b32 %[T], -|%[T]|, v124, s[62:63]\n"
-      ".Lq_acc_%=:\n"
-      "v_pk_fma_f32 %[C01], %[c01], v[124:125], %[C01] op_sel:[0,1,0]\n"
-      "v_fmac_f32 %[C2], %[c2], v125\n"
-      ".Lq_end_%=:\n"
-      : [T] "+v"(T), [C01] "+v"(C01), [C2] "+v"(C2), [last] "+v"(last)
-      : [G] "v"(G), [A] "v"(A), [BC] "v"(BC), [o] "v"(o), [c01] "v"(c01), [c2] "v"(c2),
-        [hidx] "v"(hidx), [P] "v"(P), [amin] "s"(alpha_min), [amax] "s"(alpha_max), [tmin] "s"(t_min),
-        [qm] "s"(qm), [fast] "s"(fast), [k] "n"(K)
-      : "vcc", "scc", "s62", "s63", "v122", "v123", "v124", "v125", "v126", "v127");
-}
 
 // Inner loop (the result of the round-2 A/B series, profiles/r2_tiles_variants_ab.txt; the superseded
 // variants are in the history before this commit):
@@ -303,18 +234,18 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const uint32_t* list = point_list + l_start;
 
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  int px[QW], py[QW]; f32x2 pxy[QW]; bool live[QW];     // pxy: the pixel centre as a register pair
-  float T[QW], C2[QW]; f32x2 C01[QW]; uint32_t last[QW];   // C01: colour channels 0, 1 as a pair
+  int px[QW], py[QW]; float pxf[QW], pyf[QW]; bool live[QW];
+  float T[QW], C0[QW], C1[QW], C2[QW]; uint32_t last[QW];
   bool any_live = false;
 #pragma unroll
   for (int k = 0; k < QW; ++k) {
     const int q = q_first + k;
     px[k] = tx * kTile + 8 * (q & 1) + (lane & 7);
     py[k] = ty * kTile + 8 * (q >> 1) + (lane >> 3);
-    pxy[k] = f32x2{(float)px[k], (float)py[k]};
+    pxf[k] = (float)px[k]; pyf[k] = (float)py[k];
     live[k] = px[k] < W && py[k] < H;
     any_live |= live[k];
-    T[k] = 1.f; C01[k] = f32x2{0.f, 0.f}; C2[k] = 0.f; last[k] = 0;
+    T[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f; last[k] = 0;
   }
   uint32_t b_head = 0, b_tail = 0;  // wave-uniform ring cursors
   const uint64_t lt = lanemask_lt();
@@ -326,50 +257,35 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   float Ts[QW];
 #pragma unroll
   for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
-  // Stop-free windows.  A pixel can only stop at an entry when T (1 - alpha) < t_min, alpha <= the
-  // entry's opacity: with om = the largest opacity among the ring's entries, no pixel with
-  // T >= t_floor = t_min / (1 - om)^8 can stop within the next 8 (kFwdWin) entries.  Every 8 entries ONE
-  // compare per quadrant asks "is every pixel of the quadrant live with T >= t_floor" (bit k of fastq,
-  // wave-uniform); inside such a window a plain entry (entry_is_plain) takes the SHORT form of the
-  // update: no sign test of the power, no alpha_max clamp, no max(T, 0), no stop test, no selects on
-  // the weight and the transmittance -- 14 full-rate + 3 half-rate + 1 transcendental instruction
-  // per quadrant evaluation instead of 9 + 9 + 1 + 4 packed: 64 instead of 94 issue cycles in the same
-  // harness (tools/issue_model.hip `seq` rows, profiles/r3_issue_model.txt).  84 % of the quadrant
-  // evaluations of BASELINE configs[1] qualify (opacities <= 1/3: t_floor = 2.5e-3).
-  // BOTH forms are written out instruction by instruction with every per-pixel value updated in
-  // place: with one form left to the compiler, the two lived in different physical registers and
-  // each switch cost a copy of the whole per-pixel state (measured: +60 M instructions per launch,
-  // 0.89 -> 1.12 ms, profiles/r3_forward_forms_ab.txt).
-  float om_run = 0.f, t_floor = __builtin_inff();   // largest opacity in the ring; the windows' floor
-  uint32_t fastq = 0;                                // bit k: quadrant k is inside a stop-free window
-  auto refresh_fast = [&]() {
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < QW; ++k) m |= __any(Ts[k] < t_floor) ? 0u : (1u << k);   // (Ts < 0: stopped)
-    fastq = PS_NO_FAST ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane(m);   // (wave-uniform: say so)
-  };
   // one ring entry against the (up to QW) quadrants of this wave it can reach
   auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
     const uint32_t hidx = __float_as_uint(q2.y);
 #if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
 #else
-    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+    // (one quadrant per wave: every ring entry reaches it, no mask to test)
+    const uint32_t qm = QW == 1 ? 1u : __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #endif
-    const uint32_t fast = (uint32_t)__builtin_amdgcn_readfirstlane((qm & kPlainBit) ? fastq : 0u);
-    // (forward_quadrant: ONE asm statement per quadrant with the quadrant skip, the shared evaluation of
-    // the power and both tails behind wave-uniform branches)
-    const f32x2 G = f32x2{q0.x, q0.y}, BC = f32x2{q0.w, q1.x}, c01 = f32x2{q1.z, q1.w};
-    forward_quadrant<0>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[0], alpha_min, alpha_max, t_min,
-                        Ts[0], C01[0], C2[0], last[0]);
-    if constexpr (QW > 1)
-      forward_quadrant<1>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[1], alpha_min, alpha_max,
-                          t_min, Ts[1], C01[1], C2[1], last[1]);
-    if constexpr (QW > 2) {
-      forward_quadrant<2>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[2], alpha_min, alpha_max,
-                          t_min, Ts[2], C01[2], C2[2], last[2]);
-      forward_quadrant<3>(qm, fast, G, q0.z, BC, q1.y, c01, q2.x, hidx, pxy[3], alpha_min, alpha_max,
-                          t_min, Ts[3], C01[3], C2[3], last[3]);
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+      if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
+        const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
+        const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
+        const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
+        const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+        const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
+        const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+        float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
+        asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
+        const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
+        const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
+        const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
+        Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
+        C0[k] = fmaf(q1.z, wgt, C0[k]);
+        C1[k] = fmaf(q1.w, wgt, C1[k]);
+        C2[k] = fmaf(q2.x, wgt, C2[k]);
+        last[k] = (ok & !stop) ? hidx : last[k];
+      }
     }
   };
   auto every_pixel_stopped = [&]() {
@@ -381,7 +297,6 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   auto blend1 = [&](uint32_t m) {
     uint32_t slot = b_head & (kQB - 1);
     float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-    refresh_fast();                                  // the first window of this call
     for (uint32_t j = 0; j < m; j += 2) {
       slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
       const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
@@ -390,10 +305,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       slot = (b_head + j + 2) & (kQB - 1);
       a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
       process_entry(b0, b1, b2);
-      if ((j & (uint32_t)(kFwdWin - 1)) == (uint32_t)(kFwdWin - 2)) {   // next window; termination
-        refresh_fast();
-        if (fastq == 0u && every_pixel_stopped()) { all_done = true; break; }
-      }
+      if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
     }
     b_head += m;
     wave_lds_sync();
@@ -421,7 +333,6 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
         id2 = idx_of(first + 2 * kBatch);
       }
       bool keep = false;
-      float op_keep = 0.f;
       float4 q0, q1, q2;
       if ((uint32_t)lane < m) {
         const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
@@ -429,29 +340,16 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                                     : quadrant_mask_part<QW>(r0.x, r0.y, A, B, Cq, r1.y, alpha_min,
                                                              x0, y0, q_first);
         keep = qm != 0u;
-        const uint32_t plain = entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max) ? kPlainBit : 0u;
         q0 = make_float4(r0.x, r0.y, A, B);
         q1 = make_float4(Cq, r1.y, r2.x, r2.y);
-        q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm | plain), 0.f);
-        op_keep = keep ? r1.y : 0.f;
+        q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
       }
       const uint64_t mask = __ballot(keep);
       if (keep) {
         const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
         lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
       }
-      const bool ring_was_empty = b_tail == b_head;
       b_tail += (uint32_t)__popcll(mask);
-      // largest opacity over the entries the ring holds: a running value, reset when the ring runs
-      // empty (leftovers can outlive several refine batches that kept nothing)
-      if (ring_was_empty) om_run = 0.f;
-      om_run = fmaxf(om_run, __uint_as_float(wave_max_u(__float_as_uint(op_keep))));   // (>= 0: bits order)
-      {
-        const float om = fminf(om_run, alpha_max);
-        // t_min / (1 - om)^8, rounded up a little; om -> 1 gives +inf (never stop-free)
-        t_floor = 1.0001f * t_min * fast_exp2(-(float)kFwdWin * __log2f(1.f - om));
-        t_floor = (t_floor == t_floor) ? t_floor : __builtin_inff();
-      }
       wave_lds_sync();
       // full batches while the list lasts, then whatever is left (ONE call site: the blend loop
       // is instantiated once)
@@ -475,8 +373,8 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     if (px[k] < W && py[k] < H) {
       const size_t pix = (size_t)py[k] * W + px[k];
       float* oc = out_color + (size_t)v * 3 * P;
-      oc[pix] = C01[k].x + T[k] * bg0;
-      oc[P + pix] = C01[k].y + T[k] * bg1;
+      oc[pix] = C0[k] + T[k] * bg0;
+      oc[P + pix] = C1[k] + T[k] * bg1;
       oc[2 * P + pix] = C2[k] + T[k] * bg2;
       final_T[(size_t)v * P + pix] = T[k];
       n_contrib[(size_t)v * P + pix] = last[k];
