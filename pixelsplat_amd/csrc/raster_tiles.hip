@@ -27,12 +27,14 @@
 #endif
 // Quadrants per forward wave: 4 = one wave per 16x16 tile (4 pixels per lane); 2 = two waves per tile
 // (top / bottom half, 2 pixels per lane); 1 = one wave per 8x8 quadrant.  Fewer quadrants per wave =
-// more, smaller tasks (the launch tail of 7168 tile tasks on 4096 wave slots costs the 4-quadrant
-// kernel ~14 % at BASELINE configs[1]) and fewer registers (more waves per SIMD), paid for with a
-// refine pass per wave over the tile's whole list.  Results are identical by construction (a
-// pixel's walk does not depend on which wave owns it).
+// more, smaller tasks (7168 tile tasks on 4096 wave slots leave a launch tail that costs the
+// 4-quadrant kernel ~14 % at BASELINE configs[1]) and fewer registers (more waves per SIMD), paid for
+// with a refine pass per wave over the tile's whole list.  Results are identical by construction (a
+// pixel's walk does not depend on which wave owns it).  Measured (profiles/r3_forward_split_ab.txt,
+// configs[1]): 4 quadrants 0.93 ms, 2 quadrants 0.87 ms (5 or 6 waves per SIMD alike), 1 quadrant
+// 0.86-0.87 ms with four times the record gathers: 2 is the default.
 #ifndef PS_FWD_QW
-#define PS_FWD_QW 4
+#define PS_FWD_QW 2
 #endif
 
 namespace ps {
@@ -196,7 +198,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
 //     is refined and blended.
 #ifndef PS_FWD_MIN_WAVES
-#define PS_FWD_MIN_WAVES (PS_FWD_QW == 4 ? 4 : 6)   // waves per SIMD the register allocation aims at
+#define PS_FWD_MIN_WAVES (PS_FWD_QW == 4 ? 4 : 5)   // waves per SIMD the register allocation aims at
 #endif
 __global__ void __launch_bounds__(kWavesPerBlock* kWave, PS_FWD_MIN_WAVES)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
