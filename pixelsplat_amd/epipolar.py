@@ -122,22 +122,23 @@ def gemm_tn(a: Tensor, b: Tensor, colsum: bool = False):
     return (c, cs) if colsum else c
 
 
-# weight gradients of the per-ray GEMMs on the stream the folded weights live on (PS_WGRAD_SIDE=0: on
-# the main stream, as in round 2)
-WGRAD_ON_SIDE_STREAM = _os.environ.get("PS_WGRAD_SIDE", "1") != "0"
+# PS_WGRAD_SIDE=1: weight gradients of the per-ray GEMMs on the stream the folded weights live on.
+# Measured and NOT the default (profiles/r3_forward_forms_ab.txt, call 2): next to the VALU-bound
+# kernels of the main stream the split-k MFMA kernel takes 0.126 instead of 0.107 ms and slows its
+# neighbours by more than it hides -- (A) 3.46 vs 3.38 ms.
+WGRAD_ON_SIDE_STREAM = _os.environ.get("PS_WGRAD_SIDE", "0") == "1"
 
 
 class _RayLinear(torch.autograd.Function):
     """y = x W^T (+ bias) over all rays; the weight gradient dW = dy^T x is the long-k GEMM
     hipBLASLt handles badly (gemm_tn.hip).
 
-    `wgrad_stream`: the stream the consumer of dW runs on -- for the folded attention weights the
-    side stream of `EpipolarTransformer.fold_layers` (autograd replays `_FoldWeights.backward` on the
-    stream of its forward).  The split-k GEMM is then launched THERE, behind the main stream's dy:
-    it is an MFMA kernel with nothing downstream on the main stream, so it runs under the VALU-bound
-    kernels that follow (attention backward of the previous layer, the feature-map gradient)
-    instead of between them.  Ordering: same-stream FIFO with its consumer; dy and x are kept alive
-    for the side stream (`record_stream`)."""
+    `wgrad_stream` (used only with PS_WGRAD_SIDE=1, an experiment that did not pay -- see
+    WGRAD_ON_SIDE_STREAM): the stream the consumer of dW runs on -- for the folded attention weights
+    the side stream of `EpipolarTransformer.fold_layers` (autograd replays `_FoldWeights.backward`
+    on the stream of its forward).  The split-k GEMM is then launched THERE, behind the main stream's
+    dy.  Ordering: same-stream FIFO with its consumer; dy and x are kept alive for the side stream
+    (`record_stream`)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, wgrad_stream=None):

@@ -29,3 +29,7 @@ python tools/pmc_summary.py $out/${tag}_pmc1/*counter_collection.csv $out/${tag}
 python tools/pmc_sq_summary.py $out/${tag}_pmc3/*counter_collection.csv $out/${tag}_pmc4/*counter_collection.csv > $out/${tag}_pmc_sq.json 2>> $out/${tag}_prof.log
 rm -rf $out/${tag}_pmc[1-4] $out/${tag}_prof   # raw traces are large; the summaries stay
 head -c 400 $out/${tag}_bench.json; echo
+# roctx ranges of the same step as rocprofv3 --marker-trace sees them (kernel trace beside it, no counters)
+PS_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $out/${tag}_roctx -o p -- python bench.py $args --steps 3 --warmup 1 --no-cpu-baseline --no-probes --launch eager > $out/${tag}_roctx.log 2>&1
+f=$(ls $out/${tag}_roctx/*marker_api_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_roctx_ranges.csv
+rm -rf $out/${tag}_roctx
