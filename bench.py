@@ -575,6 +575,7 @@ def main():
     rank_ms = P.gather_over_ranks(elapsed_local / args.steps * 1e3, world, dev)
     exposed = reducer.exposed_ms(last=args.steps)
     launches_before_finish = reducer.stats["launches_before_finish"]
+    launches_so_far = reducer.stats["launches"]
     eager_ms = elapsed / args.steps * 1e3
     if launch_mode == "hipgraph":
         # events cannot be read from inside a replayed graph: the same kernels are timed in an
@@ -746,6 +747,7 @@ def main():
                 # collectives of the timed steps launched BEFORE finish() (from the gradient hooks /
                 # reduce_now, i.e. under the rasterizer's backward) and what finish() still waited
                 "launches_before_finish_total": launches_before_finish,
+                "launches_total_at_end_of_timed_region": launches_so_far,
                 "exposed_ms_per_step": (round(sum(exposed) / len(exposed), 4) if exposed else 0.0),
                 "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
                                      "all": [round(x, 3) for x in rank_ms]},

@@ -1,0 +1,51 @@
+"""The N > 1 path of bench.py end to end on the GPU box: two ranks on ONE device over gloo
+(PIXELSPLAT_DIST_BACKEND=gloo: RCCL refuses two ranks on the same device; the pool has one GPU per
+box), the small BASELINE configs[0] workload, both launch modes.  What this covers that the CPU
+tests cannot: the gradient hooks / reduce_now() next to hipGraph capture and replay, the bucket
+launches landing BEFORE finish() in the eager schedule, the rank-consistent launch-mode decision, the
+communicator fields of the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*extra):
+    env = dict(os.environ, PIXELSPLAT_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--size", "64", "--batch", "1", "--no-cpu-baseline", "--no-probes", *extra]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 alone prints the line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["eager", "auto"])
+def test_two_ranks_on_one_device(gpu_device, mode):
+    rec = _bench("--launch", mode)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    comm = rec["comm"]
+    assert comm["world_size"] == 2 and comm["rccl_nranks"] == 2 and comm["backend"] == "gloo"
+    assert len(comm["rank_ms_per_step"]["all"]) == 2
+    assert comm["rank_ms_per_step"]["max"] == pytest.approx(rec["ms_per_step"], rel=0.05)
+    assert comm["buckets"] >= 1 and comm["launches_total_at_end_of_timed_region"] >= 4 * comm["buckets"]
+    # the step's views of BOTH ranks over the slowest rank's time
+    assert rec["value"] == pytest.approx(2 * 4 / (rec["ms_per_step"] * 1e-3), rel=1e-3)
+    if mode == "eager":
+        assert rec["launch"] == "eager"
+        # every bucket of the path's parameters completes from the hooks, under (B): none is left
+        # for finish() (the feed-forward PreNorm had kept the bucket incomplete)
+        assert comm["launches_before_finish_total"] == comm["launches_total_at_end_of_timed_region"]
+    else:
+        assert rec["launch"] in ("hipgraph", "eager")
+        if rec["launch"] == "eager":
+            assert rec["launch_fallback"]                  # a fallback must say why
+        assert rec["paths"]["eager_ms_per_step"] > 0
