@@ -455,9 +455,11 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* desc, int32_t n_layers,
  * instead of once per tile its line crosses: 2.5x less memory-side traffic and 1.6x less time
  * at the paper configuration. */
 size_t ps_epipolar_token_grad_floats(const PsEpipolarDesc* desc);
-/* uint32 words `ray_boxes` must hold for the two-pass call: one packed pixel box per (ray, other
- * view) + a work estimate and a slot of the longest-first block order per 4x4 tile of every map
- * (the single-pass calls need only the first b*v*(v-1)*h*w words). */
+/* uint32 words `ray_boxes` must hold for the two-pass call: the scratch of its binned gather -- per
+ * (source map, block of 256 tokens, 4x4 tile) counts, per tile a length, an offset and a slot of the
+ * longest-first block order, and the per-tile token lists (at most 4 entries per token) -- or, for
+ * the round-2 gather, one packed pixel box per (ray, other view) + two words per tile (the
+ * single-pass calls need only the first b*v*(v-1)*h*w words). */
 size_t ps_epipolar_ray_box_words(const PsEpipolarDesc* desc);
 int ps_epipolar_feature_grad_two_pass(const PsEpipolarDesc* desc, int32_t n_layers,
                                       const float* xy_sample, const uint8_t* flags,

@@ -23,6 +23,9 @@
 #endif
 // PS_ABLATE_DFMAP (same kind of experiment on the two-pass feature-map gradient's gather kernel):
 // 1: the walk without its LDS read-modify-writes, 2: without the token-row loads
+#ifndef PS_DFMAP_BINNED
+#define PS_DFMAP_BINNED 1     // 0: the round-2 gather (every tile sweeps the casting view's rays)
+#endif
 #ifndef PS_ABLATE_DFMAP
 #define PS_ABLATE_DFMAP 0
 #endif
@@ -1369,6 +1372,328 @@ epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
+// Binned gather (round 3): the per-tile token lists are BUILT once per flush by a stable count /
+// scan / fill pass over the tokens -- the rasterizer's binning scheme -- instead of being
+// re-discovered by every tile with a sweep over all rays of the casting view.
+//
+//   count   a block = 256 consecutive tokens (ray-major, sample-minor) of one (casting view, other
+//           view) pair: every token's bilinear footprint touches 1, 2 or 4 tiles of the source map;
+//           an LDS histogram per block, written out as one row cnt[src][block][tile];
+//   scan    per (source map, tile): exclusive prefix over the map's blocks (in place), the tile's
+//           length; then one block orders the tiles longest first and turns the lengths into
+//           global offsets;
+//   fill    the same blocks again: per-wave counts -> per-(wave, tile) start = tile offset + block
+//           prefix + earlier waves; inside a wave the rank of a token among the lanes with the same
+//           tile (wave64 match by ballots, as in the radix sort), footprint slot by slot;
+//   gather  a block per tile walks ITS list, a contiguous quarter per wave: lanes <-> list entries
+//           for the sample position / corner records, then row by row as before.
+// The order inside a tile's list -- (casting view, block, wave, footprint slot, lane) -- depends on
+// the geometry of that source map only: the gradient is bit-reproducible and a batched launch equals
+// single-scene launches bit for bit (tests/test_epipolar_gpu.py).
+// ------------------------------------------------------------------------------------
+constexpr int kBinTokens = 256;          // tokens per count / fill block
+
+struct BinDims {
+  int tiles_x, tiles_y, tiles;           // TS x TS tiles per map
+  int blocks_per_pair;                   // count / fill blocks per (casting view, other view) pair
+  int blocks_per_src;                    // = (v - 1) * blocks_per_pair
+  int n_src;                             // b * v source maps
+};
+template <int TS>
+__host__ __device__ inline BinDims make_bin_dims(const AttnDims& dm) {
+  BinDims bd;
+  bd.tiles_x = (dm.w + TS - 1) / TS; bd.tiles_y = (dm.h + TS - 1) / TS;
+  bd.tiles = bd.tiles_x * bd.tiles_y;
+  bd.blocks_per_pair = (dm.h * dm.w * dm.s + kBinTokens - 1) / kBinTokens;
+  bd.blocks_per_src = (dm.v - 1) * bd.blocks_per_pair;
+  bd.n_src = dm.b * dm.v;
+  return bd;
+}
+
+// the (up to 4) distinct tiles of a token's bilinear footprint; returns their number
+template <int TS>
+__device__ __forceinline__ int footprint_tiles(const AttnDims& dm, const BinDims& bd, float x, float y,
+                                               int (&tile)[4]) {
+  const Corner k = corner_of(x, y, dm.w, dm.h);
+  const bool xin0 = k.x0 >= 0 && k.x0 < dm.w, xin1 = k.x0 + 1 >= 0 && k.x0 + 1 < dm.w;
+  const bool yin0 = k.y0 >= 0 && k.y0 < dm.h, yin1 = k.y0 + 1 >= 0 && k.y0 + 1 < dm.h;
+  const int tx0 = xin0 ? k.x0 / TS : -1, tx1 = xin1 ? (k.x0 + 1) / TS : -1;
+  const int ty0 = yin0 ? k.y0 / TS : -1, ty1 = yin1 ? (k.y0 + 1) / TS : -1;
+  // candidate tile columns / rows (deduplicated: the two corners of a side share a tile unless the
+  // side crosses a tile boundary)
+  int txs[2] = {0, 0}, tys[2] = {0, 0}, nx = 0, ny = 0;
+  if (tx0 >= 0) txs[nx++] = tx0;
+  if (tx1 >= 0 && tx1 != tx0) txs[nx++] = tx1;
+  if (ty0 >= 0) tys[ny++] = ty0;
+  if (ty1 >= 0 && ty1 != ty0) tys[ny++] = ty1;
+  int n = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool on = i < nx && j < ny;
+      tile[2 * j + i] = on ? tys[j < ny ? j : 0] * bd.tiles_x + txs[i < nx ? i : 0] : -1;
+      n += on;
+    }
+  return n;
+}
+
+// token `idx` (0 .. R*s) of block `blk` of pair (bv, ov): its source map, its row in cnt, its tiles
+struct BinToken { bool on; uint32_t tok; int tile[4]; };
+template <int TS>
+__device__ __forceinline__ BinToken bin_token(const AttnDims& dm, const BinDims& bd, int pair, int blk,
+                                              int t, const float* __restrict__ xy,
+                                              const uint8_t* __restrict__ flags) {
+  const int R = dm.h * dm.w;
+  const int idx = blk * kBinTokens + t;                 // (ray, sample) of the pair
+  BinToken o;
+  o.on = idx < R * dm.s;
+  const int r = o.on ? idx / dm.s : 0, smp = o.on ? idx - r * dm.s : 0;
+  const size_t ro = (size_t)pair * R + r;
+  o.tok = (uint32_t)(ro * dm.s + smp);
+  o.on = o.on && (flags[ro] & 1);
+  const float2 p = *reinterpret_cast<const float2*>(xy + 2 * (size_t)o.tok);
+  const int n = footprint_tiles<TS>(dm, bd, p.x, p.y, o.tile);
+  (void)n;
+  if (!o.on) { o.tile[0] = o.tile[1] = o.tile[2] = o.tile[3] = -1; }
+  return o;
+}
+
+// source map and position of a pair's blocks among the blocks of that map: pair = (bv, ov) with
+// bv = b * V + v (casting view v), ov the index of the other view; the maps' lists run over the
+// casting views in increasing v
+__device__ __forceinline__ void pair_source(const AttnDims& dm, int pair, int& src, int& slot) {
+  const int ovn = dm.v - 1;
+  const int bv = pair / ovn, ov = pair - bv * ovn;
+  const int v = bv % dm.v, b0 = bv - v;
+  const int sv = ov < v ? ov : ov + 1;                  // the other (source) view
+  src = b0 + sv;
+  slot = v < sv ? v : v - 1;                            // index of v among the views != sv
+}
+
+template <int TS>
+__global__ void __launch_bounds__(kBinTokens)
+epipolar_bin_count_kernel(AttnDims dm, const float* __restrict__ xy,
+                          const uint8_t* __restrict__ flags, uint32_t* __restrict__ cnt) {
+  extern __shared__ uint32_t hist[];                    // [tiles]
+  const BinDims bd = make_bin_dims<TS>(dm);
+  const int pair = blockIdx.x / bd.blocks_per_pair, blk = blockIdx.x % bd.blocks_per_pair;
+  for (int i = threadIdx.x; i < bd.tiles; i += kBinTokens) hist[i] = 0u;
+  __syncthreads();
+  const BinToken k = bin_token<TS>(dm, bd, pair, blk, threadIdx.x, xy, flags);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k.tile[j] >= 0) atomicAdd(&hist[k.tile[j]], 1u);
+  __syncthreads();
+  int src, slot;
+  pair_source(dm, pair, src, slot);
+  uint32_t* row = cnt + ((size_t)src * bd.blocks_per_src + (size_t)slot * bd.blocks_per_pair + blk) * bd.tiles;
+  for (int i = threadIdx.x; i < bd.tiles; i += kBinTokens) row[i] = hist[i];
+}
+
+// thread = (source map, tile): exclusive prefix of its counts over the map's blocks, in place;
+// loads in batches of 16 (a plain running loop is a chain of blocks_per_src dependent round trips)
+__global__ void __launch_bounds__(256)
+epipolar_bin_scan_kernel(int n_src, int tiles, int blocks_per_src, uint32_t* __restrict__ cnt,
+                         uint32_t* __restrict__ tile_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_src * tiles) return;
+  const int src = i / tiles, tile = i - src * tiles;
+  uint32_t* col = cnt + (size_t)src * blocks_per_src * tiles + tile;
+  uint32_t run = 0;
+  for (int b0 = 0; b0 < blocks_per_src; b0 += 16) {
+    uint32_t t16[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t16[k] = col[(size_t)min(b0 + k, blocks_per_src - 1) * tiles];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (b0 + k < blocks_per_src) { col[(size_t)(b0 + k) * tiles] = run; run += t16[k]; }
+  }
+  tile_len[i] = run;
+}
+
+// one block: global exclusive offsets of the n tiles' lists (tile index order)
+__global__ void __launch_bounds__(1024)
+epipolar_bin_offsets_kernel(int n, const uint32_t* __restrict__ tile_len, uint32_t* __restrict__ tile_off) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int i0 = t * per, i1 = min(i0 + per, n);
+  uint32_t sum = 0;
+  for (int i = i0; i < i1; ++i) sum += tile_len[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t y = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += y;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;
+  for (int i = i0; i < i1; ++i) { tile_off[i] = run; run += tile_len[i]; }
+}
+
+template <int TS>
+__global__ void __launch_bounds__(kBinTokens)
+epipolar_bin_fill_kernel(AttnDims dm, const float* __restrict__ xy, const uint8_t* __restrict__ flags,
+                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tile_off,
+                         uint32_t* __restrict__ list) {
+  extern __shared__ uint32_t lds[];                     // [4 waves][tiles] counts, then running starts
+  constexpr int NW = kBinTokens / kWave;
+  const BinDims bd = make_bin_dims<TS>(dm);
+  const int pair = blockIdx.x / bd.blocks_per_pair, blk = blockIdx.x % bd.blocks_per_pair;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < NW * bd.tiles; i += kBinTokens) lds[i] = 0u;
+  __syncthreads();
+  const BinToken k = bin_token<TS>(dm, bd, pair, blk, threadIdx.x, xy, flags);
+  uint32_t* mine = lds + (size_t)w * bd.tiles;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k.tile[j] >= 0) atomicAdd(&mine[k.tile[j]], 1u);
+  __syncthreads();
+  int src, slot;
+  pair_source(dm, pair, src, slot);
+  const uint32_t* row = cnt + ((size_t)src * bd.blocks_per_src + (size_t)slot * bd.blocks_per_pair + blk) * bd.tiles;
+  const uint32_t* toff = tile_off + (size_t)src * bd.tiles;
+  for (int i = threadIdx.x; i < bd.tiles; i += kBinTokens) {
+    uint32_t run = toff[i] + row[i];                    // list start of (tile, this block)
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const uint32_t c = lds[(size_t)ww * bd.tiles + i];
+      lds[(size_t)ww * bd.tiles + i] = run;             // start of (tile, wave)
+      run += c;
+    }
+  }
+  __syncthreads();
+  // footprint slot by slot: rank among the wave's lanes with the same tile (match by ballots over
+  // the 12 bits of a tile index: maps <= 255 x 255, tiles <= 64 x 64), the leader advances the start
+  const uint64_t lt = lanemask_lt();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool on = k.tile[j] >= 0;
+    const uint32_t tl = on ? (uint32_t)k.tile[j] : 0u;
+    uint64_t mask = __ballot(on);
+#pragma unroll
+    for (int bit = 0; bit < 12; ++bit) {
+      const bool b1 = (tl >> bit) & 1u;
+      const uint64_t bal = __ballot(b1);
+      mask &= b1 ? bal : ~bal;
+    }
+    if (on) {
+      const uint32_t start = mine[tl];
+      const uint32_t r = (uint32_t)__popcll(mask & lt);
+      list[start + r] = k.tok;
+      if (r == 0) mine[tl] = start + (uint32_t)__popcll(mask);
+    }
+    wave_lds_sync();
+  }
+}
+
+template <int CPL, int TS>
+__global__ void __launch_bounds__(kDfWaves* kWave)
+epipolar_dfmap_list_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
+                                  const uint32_t* __restrict__ tile_len,
+                                  const uint32_t* __restrict__ tile_off,
+                                  const uint32_t* __restrict__ list, const float* __restrict__ tg,
+                                  const uint32_t* __restrict__ order, float* __restrict__ dfmap) {
+  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][TS*TS pixels + dummy][c]
+  using V = typename LaneVec<CPL>::type;
+  const int R = dm.h * dm.w;
+  const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
+  if ((int)blockIdx.x >= n_work) return;
+  const int work = (int)order[blockIdx.x];                       // longest list first
+  const int tile_id = work % (tiles_x * tiles_y);
+  const int src_bv = work / (tiles_x * tiles_y);                // (b, source view)
+  const int tx0 = (tile_id % tiles_x) * TS, ty0 = (tile_id / tiles_x) * TS;
+  const int tx1 = min(tx0 + TS, dm.w) - 1, ty1 = min(ty0 + TS, dm.h) - 1;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: say so)
+  const int c0 = lane * CPL;
+  const bool lane_c = c0 < dm.c;
+  const int cl = lane_c ? c0 : 0;
+  const int tile_floats = TS * TS * dm.c + max(dm.c, kWave * CPL);   // + dummy slots
+  float* tile = tiles + (size_t)wv * tile_floats;
+  float* lane_base = tile + (lane_c ? 0 : TS * TS * dm.c) + c0;
+  const int lane_mul = lane_c ? 1 : 0;
+  for (int i = lane; i < tile_floats; i += kWave) tile[i] = 0.f;
+  wave_lds_sync();
+
+  // this wave's contiguous quarter of the tile's list
+  const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_len[work]);
+  const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_off[work]);
+  const uint32_t per = (len + kDfWaves - 1) / kDfWaves;
+  const uint32_t i_begin = min(len, (uint32_t)wv * per), i_end = min(len, ((uint32_t)wv + 1) * per);
+  const uint32_t* mine = list + off0;
+  for (uint32_t i0 = i_begin; i0 < i_end; i0 += kWave) {
+    const uint32_t n_here = min((uint32_t)kWave, i_end - i0);
+    // lanes <-> list entries: token, sample position, the four corner records relative to the tile
+    const bool tok_on = (uint32_t)lane < n_here;
+    const uint32_t tok = mine[tok_on ? i0 + lane : i_begin];
+    const float2 p = *reinterpret_cast<const float2*>(xy + 2 * (size_t)tok);
+    const Corner kq = corner_of(p.x, p.y, dm.w, dm.h);
+    int off[4]; float wt[4];
+#pragma unroll
+    for (int cr = 0; cr < 4; ++cr) {
+      const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
+      const bool in = tok_on && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
+      const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
+      off[cr] = (in ? (yy - ty0) * TS + (xx - tx0) : TS * TS) * dm.c;
+      wt[cr] = in ? wx * wy : 0.f;
+    }
+    // rows kDfTokGroup at a time: all loads of a group issued before the first read-modify-write
+    for (uint32_t t0 = 0; t0 < n_here; t0 += kDfTokGroup) {
+      float df[kDfTokGroup][CPL];
+#pragma unroll
+      for (int q = 0; q < kDfTokGroup; ++q) {
+        const uint32_t tq = min(t0 + q, n_here - 1);            // (clamped: loaded, not used)
+        const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)tq);
+        load_cpl<CPL>(tg + (size_t)tk * dm.c + cl, df[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < kDfTokGroup; ++q) {
+        if (t0 + q < n_here) {
+          const int tl = (int)(t0 + q);
+          V* dst[4]; V val[4];
+#pragma unroll
+          for (int cr = 0; cr < 4; ++cr) {
+            dst[cr] = reinterpret_cast<V*>(lane_base + lane_bcast_i(off[cr], tl) * lane_mul);
+            val[cr] = *dst[cr];
+          }
+#pragma unroll
+          for (int cr = 0; cr < 4; ++cr) {
+            const float wgt = lane_bcast(wt[cr], tl);
+            float* f = reinterpret_cast<float*>(&val[cr]);
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[q][i], f[i]);
+            *dst[cr] = val[cr];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = dfmap + (size_t)src_bv * R * dm.c;
+  const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+  for (int i = threadIdx.x; i < tw * th * dm.c; i += kDfWaves * kWave) {
+    const int pix = i / dm.c, ch = i - pix * dm.c;
+    const int py = pix / tw, px = pix - py * tw;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDfWaves; ++k)
+      acc += tiles[(size_t)k * tile_floats + (py * TS + px) * dm.c + ch];
+    out[((size_t)(ty0 + py) * dm.w + tx0 + px) * dm.c + ch] = acc;
+  }
+}
+
+// uint32 words of scratch the binned gather needs (layout: cnt | tile_len | tile_off | order | list)
+size_t epipolar_bin_words(const AttnDims& dm) {
+  const BinDims bd = make_bin_dims<4>(dm);
+  const size_t n_tiles = (size_t)bd.n_src * bd.tiles;
+  const size_t tokens = (size_t)dm.b * dm.v * (dm.v - 1) * dm.h * dm.w * dm.s;
+  return (size_t)bd.n_src * bd.blocks_per_src * bd.tiles + 3 * n_tiles + 4 * tokens;
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 static size_t attn_smem(const AttnDims& dm) {
@@ -1476,21 +1801,51 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
   constexpr int TS = 4;
   const int tiles = ((dm.w + TS - 1) / TS) * ((dm.h + TS - 1) / TS);
   const int n_work = dm.b * dm.v * tiles;
-  // two passes: the words behind the n_ro boxes hold the tile work estimates and the block order
-  uint32_t* tile_work = token_grad != nullptr ? boxes + n_ro : nullptr;
-  uint32_t* order = token_grad != nullptr ? boxes + n_ro + n_work : nullptr;
-  if (tile_work != nullptr &&
-      hipMemsetAsync(tile_work, 0, (size_t)n_work * sizeof(uint32_t), st) != hipSuccess)
-    return PS_ERR_LAUNCH;
-  hipLaunchKernelGGL(epipolar_ray_box_kernel<TS>, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
-                     tile_work != nullptr ? (size_t)tiles * sizeof(uint32_t) : 0, st, dm, xy, flags,
-                     boxes, tile_work);
   dim3 g2((unsigned)((n_work + 7) / 8 * 8)), b2(kDfWaves * kWave);
   const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
   const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
   const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
   if (token_grad != nullptr) {     // two passes: token gradients once, then the tile gather
     dim3 g1((unsigned)((n_ro + 3) / 4)), b1(256);
+#if PS_DFMAP_BINNED
+    // binned gather: the per-tile token lists first (count / scan / offsets + order / fill), from the
+    // geometry alone; `boxes` is the scratch: cnt | tile_len | tile_off | order | list
+    const BinDims bd = make_bin_dims<TS>(dm);
+    uint32_t* cnt = boxes;
+    uint32_t* tile_len = cnt + (size_t)bd.n_src * bd.blocks_per_src * bd.tiles;
+    uint32_t* tile_off = tile_len + n_work;
+    uint32_t* order = tile_off + n_work;
+    uint32_t* list = order + n_work;
+    const unsigned bin_blocks = (unsigned)(dm.b * dm.v * (dm.v - 1) * bd.blocks_per_pair);
+    hipLaunchKernelGGL(epipolar_bin_count_kernel<TS>, dim3(bin_blocks), dim3(kBinTokens),
+                       (size_t)bd.tiles * sizeof(uint32_t), st, dm, xy, flags, cnt);
+    hipLaunchKernelGGL(epipolar_bin_scan_kernel, dim3((unsigned)((n_work + 255) / 256)), dim3(256), 0, st,
+                       bd.n_src, bd.tiles, bd.blocks_per_src, cnt, tile_len);
+    hipLaunchKernelGGL(epipolar_bin_offsets_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_len, tile_off);
+    hipLaunchKernelGGL(epipolar_tile_order_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_len, order);
+    hipLaunchKernelGGL(epipolar_bin_fill_kernel<TS>, dim3(bin_blocks), dim3(kBinTokens),
+                       (size_t)(kBinTokens / kWave) * bd.tiles * sizeof(uint32_t), st, dm, xy, flags, cnt,
+                       tile_off, list);
+    const size_t sm3 = (size_t)kDfWaves * tile_floats * sizeof(float);
+#define PS_TG(CPL)                                                                              \
+  do {                                                                                          \
+    if (n_layers == 1) hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 1>), g1, b1, 0, st,  \
+                                          dm, flags, L, token_grad);                            \
+    else hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 2>), g1, b1, 0, st, dm, flags, L,  \
+                            token_grad);                                                        \
+    hipLaunchKernelGGL((epipolar_dfmap_list_gather_kernel<CPL, TS>), g2, b2, sm3, st, dm,       \
+                       n_work, xy, tile_len, tile_off, list, token_grad, order, dfmap);         \
+  } while (0)
+    if (dm.c <= 64) PS_TG(1); else if (dm.c <= 128) PS_TG(2); else PS_TG(4);
+#undef PS_TG
+    return PS_OK;
+#else
+    uint32_t* tile_work = boxes + n_ro;
+    uint32_t* order = boxes + n_ro + n_work;
+    if (hipMemsetAsync(tile_work, 0, (size_t)n_work * sizeof(uint32_t), st) != hipSuccess)
+      return PS_ERR_LAUNCH;
+    hipLaunchKernelGGL(epipolar_ray_box_kernel<TS>, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
+                       (size_t)tiles * sizeof(uint32_t), st, dm, xy, flags, boxes, tile_work);
     hipLaunchKernelGGL(epipolar_tile_order_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_work,
                        order);
 #define PS_TG(CPL)                                                                              \
@@ -1505,7 +1860,11 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
     if (dm.c <= 64) PS_TG(1); else if (dm.c <= 128) PS_TG(2); else PS_TG(4);
 #undef PS_TG
     return PS_OK;
+#endif
   }
+  // single pass: the packed ray boxes only
+  hipLaunchKernelGGL(epipolar_ray_box_kernel<TS>, dim3((unsigned)((n_ro + 255) / 256)), dim3(256), 0, st,
+                     dm, xy, flags, boxes, (uint32_t*)nullptr);
 #define PS_DF(CPL, NL)                                                                          \
   hipLaunchKernelGGL((epipolar_dfmap_kernel<CPL, TS, NL>), g2, b2, sm2, st, dm, n_work, xy,     \
                      boxes, L, dfmap)

@@ -428,7 +428,9 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* d, int32_t n_layers, const fl
 size_t ps_epipolar_ray_box_words(const PsEpipolarDesc* d) {
   if (!epi_ok(d)) return 0;
   const size_t tiles = (size_t)((d->w + 3) / 4) * ((d->h + 3) / 4);
-  return (size_t)d->b * d->v * (d->v - 1) * d->h * d->w + 2 * (size_t)d->b * d->v * tiles;
+  const size_t boxes = (size_t)d->b * d->v * (d->v - 1) * d->h * d->w + 2 * (size_t)d->b * d->v * tiles;
+  const size_t binned = epipolar_bin_words(to_dims(d));     // the binned gather's lists and counters
+  return boxes > binned ? boxes : binned;
 }
 
 size_t ps_epipolar_token_grad_floats(const PsEpipolarDesc* d) {

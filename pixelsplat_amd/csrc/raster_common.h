@@ -181,6 +181,7 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                                   const float* abar, const float* dfbar, const float* dpbar,
                                   const float* dabar, float scale, float* dqt, float* du,
                                   float* de, float* ds, hipStream_t st);
+size_t epipolar_bin_words(const AttnDims& dm);   // uint32 words of scratch of the binned gather
 int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* xy,
                                  const uint8_t* flags, const float* const* qt,
                                  const float* const* attn, const float* const* dfbar,
