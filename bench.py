@@ -631,6 +631,7 @@ def main():
         if launches[i] == 0 and side_n[i]:
             tot_ms[i], launches[i] = side_ms[i], side_n[i]
 
+    comm_info = P.comm_info(world, dev)       # (a collective: every rank takes part)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = P.aggregate_throughput(V, args.steps, world, elapsed)
@@ -751,7 +752,7 @@ def main():
                 "exposed_ms_per_step": (round(sum(exposed) / len(exposed), 4) if exposed else 0.0),
                 "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
                                      "all": [round(x, 3) for x in rank_ms]},
-                **P.comm_info(world, dev),
+                **comm_info,
             },
             "whole_path": {
                 # (B)'s reference-algorithm bytes over (B)'s own step time

@@ -1173,7 +1173,10 @@ epipolar_token_grad_kernel(AttnDims dm, const uint8_t* __restrict__ flags, Fgrad
   }
 }
 
-constexpr int kDfTokGroup = 4;   // token rows in flight per wave in pass 2
+#ifndef PS_DF_TOKGROUP
+#define PS_DF_TOKGROUP 4
+#endif
+constexpr int kDfTokGroup = PS_DF_TOKGROUP;   // token rows in flight per wave in pass 2
 
 template <int CPL, int TS>
 __global__ void __launch_bounds__(kDfWaves* kWave)
