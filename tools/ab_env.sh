@@ -7,7 +7,7 @@ tag=$1; shift
 out=gpurun_out/$tag.log; : > $out
 for rep in 1 2; do
   for envs in "$@"; do
-    env $envs python bench.py ${BENCH_ARGS:-} --steps 20 --warmup 3 --no-cpu-baseline --no-probes 2>/dev/null | python -c "
+    env $envs timeout 240 python bench.py ${BENCH_ARGS:-} --steps 20 --warmup 3 --no-cpu-baseline --no-probes 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms']; n=d['kernel_launches_per_step']
 print('[%s]' % '$envs', 'step', d['ms_per_step'], 'A', d['paths']['epipolar_only_ms_per_step'], 'B', d['paths']['raster_only_ms_per_step'], {g: round(v,4) for g,v in k.items() if v*n[g] > 0.03})" >> $out 2>&1

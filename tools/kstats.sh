@@ -1,7 +1,7 @@
 # usage: tools/kstats.sh <tag> [bench args]: rocprofv3 kernel stats of a short eager bench run (step only), top kernels
 tag=$1; shift
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o p -- python bench.py $* --steps 10 --warmup 0 --no-cpu-baseline --no-probes --launch eager > gpurun_out/${tag}_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o p -- python bench.py $* --steps 10 --warmup 0 --no-cpu-baseline --no-probes --launch eager > gpurun_out/${tag}_prof.log 2>&1
 f=$(ls gpurun_out/${tag}_prof/*kernel_stats.csv | head -1); cp $f gpurun_out/${tag}_kernel_stats.csv; rm -rf gpurun_out/${tag}_prof
 python - <<PY
 import csv
