@@ -73,7 +73,9 @@ SINGLE_KERNEL_GROUPS = {
     "epipolar_attention_forward": ["epipolar_attn_forward_kernel"],
     "epipolar_attention_backward": ["epipolar_attn_backward_kernel"],
     "epipolar_feature_grad": ["epipolar_token_grad_kernel", "epipolar_dfmap_gather_kernel",
-                              "epipolar_dfmap_kernel"],
+                              "epipolar_dfmap_kernel", "epipolar_dfmap_list_gather_kernel",
+                              "epipolar_bin_count_kernel", "epipolar_bin_scan_kernel",
+                              "epipolar_bin_offsets_kernel", "epipolar_bin_fill_kernel"],
     "gaussian_adapter_backward": ["adapter_backward_kernel<4, 0>"],
     "depth_sampler_forward": ["depth_sampler_forward_kernel"],
     "depth_sampler_backward": ["depth_sampler_backward_kernel"],
