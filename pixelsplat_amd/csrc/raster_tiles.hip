@@ -1,19 +1,23 @@
-// Tile kernels: one wave64 owns one 16x16 tile, 4 pixels per lane -- pixel k of lane l sits
-// in 8x8 QUADRANT k at (l & 7, l >> 3).  Each staged entry carries a 4-bit mask of the
-// quadrants its alpha >= 1/255 ellipse can reach, so the per-entry work is skipped per
-// quadrant with wave-uniform (scalar) branches.  There is no duplicated (tile, Gaussian) key list and no global
-// sort over it.  Per tile the wave runs a two-stage, LDS-resident pipeline over its bin:
+// Tile kernels.  A 16x16 tile is four 8x8 QUADRANTS; a wave64 owns PS_FWD_QW of them in the forward
+// (default 2: two waves per tile) and all four in the backward, one pixel per lane and quadrant -- pixel
+// k of lane l sits in quadrant k at (l & 7, l >> 3).  Each staged entry carries a 4-bit mask of the
+// quadrants its alpha >= 1/255 ellipse can reach, so the per-entry work is skipped per quadrant with
+// wave-uniform (scalar) branches.  There is no duplicated (tile, Gaussian) key list and no global
+// sort over it.  Per tile a wave runs a two-stage, LDS-resident pipeline over the tile's bin:
 //
 //   list     the tile's bin (raster_bins.hip): Gaussian ids in (depth, id) order, exactly
 //            the reference's per-tile range of its sorted point list; the
 //            1-based position in it is the "contributor" index n_contrib refers to.
 //   refine   64 list entries at a time, one per lane: gather the 48-byte record and test
-//            the alpha >= 1/255 ellipse against the tile's pixel box (exact conservative
+//            the alpha >= 1/255 ellipse against the wave's quadrants (exact conservative
 //            bound: the minimum of the quadratic form over the box).  Entries that cannot
-//            reach 1/255 on any pixel of the tile are dropped -- every pixel would have
+//            reach 1/255 on any of its pixels are dropped -- every pixel would have
 //            skipped them anyway (A.3), so results are unchanged -- survivors go to ring B
 //            with exp2-scaled conic coefficients.
 //   blend    64 ring-B entries at a time, broadcast from LDS, branch-free per-pixel update.
+//
+// What was tried on these two kernels and what an instruction costs here: DESIGN.md 4 / 4a,
+// profiles/r2_tiles_variants_ab.txt, profiles/r3_{issue_model,forward_forms_ab,forward_split_ab}.txt.
 //
 // Replaces renderCUDA fwd/bwd of the external rasterizer (call site
 // /root/reference/src/model/decoder/cuda_splatting.py:117-124).
@@ -40,7 +44,7 @@
 namespace ps {
 
 #ifndef PS_NO_FAST
-#define PS_NO_FAST 0        // 1: never take the short forms (A/B of what they buy)
+#define PS_NO_FAST 0        // 1: the backward never takes its short form (A/B of what it buys)
 #endif
 constexpr int kFwdQW = PS_FWD_QW;
 constexpr int kFwdParts = 4 / kFwdQW;
@@ -145,14 +149,15 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, f
   return m;
 }
 
-// Per-entry "plain" flag (wave-uniform when the entry is blended): the conic is positive definite
-// with a condition number far from fp32 round-off (so `power > 0` cannot happen for any pixel: the
-// true power is <= -lambda_min |d|^2 and its fp32 evaluation is off by < 4e-7 lambda_max |d|^2) and the
-// opacity is below the alpha_max clamp.  Such an entry needs neither the per-pixel sign test of the
-// power nor the min() -- two of the half-rate compare / select class instructions the blend loops are
-// made of (tools/issue_model.hip: v_cmp / v_cndmask / v_min / DPP issue at ~4.4 cycles per wave64
-// instruction, v_fma / v_mul / v_add at ~2.9) -- and skipping them changes no result.
-constexpr uint32_t kPlainBit = 32u;
+// Is an entry "plain"?  Its conic is positive definite with a condition number far from fp32 round-off
+// (so `power > 0` cannot happen for any pixel: the true power is <= -lambda_min |d|^2 and its fp32
+// evaluation is off by < 4e-7 lambda_max |d|^2) and its opacity is below the alpha_max clamp.  Such an
+// entry needs neither the per-pixel sign test of the power nor the min() -- two of the half-rate
+// compare / select class instructions the blend loops are made of (tools/issue_model.hip: v_cmp /
+// v_cndmask / v_min / DPP issue at ~4.4 cycles per wave64 instruction, v_fma / v_mul / v_add at ~2.9)
+// -- and skipping them changes no result.  Used by the backward's short form (a finalisation batch
+// whose ring holds plain entries only); the forward's short form did not survive measurement
+// (DESIGN.md 4a).
 __device__ __forceinline__ bool entry_is_plain(float gx, float gy, float A, float B, float Cq,
                                                float opacity, float alpha_max) {
   const float det = 4.f * A * Cq - B * B, tr = A + Cq;
