@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""One table per benchmarked configuration out of the three committed summaries of a
+tools/profile_bench.sh run: rocprofv3 kernel stats, FETCH / WRITE counters, SQ counters.
+
+    python tools/kernel_table.py r3_c2 [r3_c4 r3_c5 ...]      -> profiles/<tag>_kernel_table.txt
+
+Algorithmic bytes are SURVEY.md 8(d)'s per-unit figures (the same formulas bench.py prices its
+`roofline` block with) for the kernels the formula names; they are per VIEW although per-scene inputs
+are read once, so a fraction above 1 is the formula's generosity, not the machine's.
+"""
+from __future__ import annotations
+
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+HBM_PEAK = 8.0e12
+
+
+def _short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)          # drop the argument list
+    return name
+
+
+def _alg_bytes(bench: dict) -> dict:
+    """kernel-name fragment -> algorithmic bytes per launch, from the bench line's own workload."""
+    cfg = bench["config"]
+    G, V, D = cfg.get("gaussians_per_scene"), cfg.get("views_per_step_per_gpu"), cfg.get("tile_list_entries_D")
+    m = re.search(r"(\d+)x(\d+), batch_size", cfg.get("workload", ""))
+    if None in (G, V, D) or not m:
+        return {}
+    npix = int(m.group(1)) * int(m.group(2))
+    return {
+        "preprocess_fused_kernel": 392.0 * G * V,
+        "tiles_forward_kernel": 36.0 * D + 20.0 * npix * V,
+        "tiles_backward_kernel": 76.0 * D + 20.0 * npix * V,
+        "geometry_backward_kernel+color_backward_kernel": 728.0 * G * V,
+    }
+
+
+def table(tag: str) -> str:
+    stats = list(csv.DictReader(open(os.path.join(PROF, f"{tag}_kernel_stats.csv"))))
+    traffic = json.load(open(os.path.join(PROF, f"{tag}_pmc_traffic.json")))
+    sq = json.load(open(os.path.join(PROF, f"{tag}_pmc_sq.json")))
+    bench_path = os.path.join(PROF, f"{tag}_bench.json")
+    bench = json.loads(open(bench_path).read().strip().splitlines()[-1]) if os.path.exists(bench_path) else {}
+    alg = _alg_bytes(bench) if bench else {}
+    tkeys = {_short(k): v for k, v in traffic["kernels"].items()}
+    skeys = {_short(k): v for k, v in sq["kernels"].items()}
+    out = [
+        f"# every ps:: kernel of the {tag} bench run: rocprofv3 average duration (profiles/{tag}_kernel_stats.csv, all",
+        f"# launches of the process incl. the side probes), memory-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE,",
+        f"# profiles/{tag}_pmc_traffic.json), the rate that makes, the algorithmic bytes of SURVEY.md 8(d) where the formula",
+        f"# names the kernel, VALU instructions per launch and VALU-busy time (profiles/{tag}_pmc_sq.json).",
+        f"# build: {traffic.get('build')}",
+        f"# git:   {traffic.get('git')}        (tools/kernel_table.py {tag})",
+        "%-58s %6s %8s %10s %6s %7s %9s %8s %8s" % ("kernel", "calls", "avg us", "traffic GB", "TB/s", "alg GB",
+                                                     "alg/8TB/s", "VALU M", "busy us"),
+    ]
+    rows = [r for r in stats if "ps::" in r["Name"]]
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    for r in rows:
+        k = _short(r["Name"])
+        avg_us = float(r["AverageNs"]) / 1e3
+        t = tkeys.get(k)
+        s = skeys.get(k)
+        tb = t["bytes"] if t else float("nan")
+        a = float("nan")
+        for frag, val in alg.items():
+            parts = frag.split("+")
+            if any(p in k for p in parts):
+                # a formula that covers two kernels is shown on each with the kernel's share of time
+                if len(parts) > 1:
+                    tot = sum(float(x["AverageNs"]) for x in rows if any(p in x["Name"] for p in parts))
+                    val = val * float(r["AverageNs"]) / tot
+                a = val
+        out.append("%-58s %6d %8.1f %10.3f %6.2f %7.3f %9.3f %8.1f %8.1f" % (
+            k[:58], int(r["Calls"]), avg_us, tb / 1e9, tb / (avg_us * 1e-6) / 1e12, a / 1e9,
+            a / (avg_us * 1e-6) / HBM_PEAK,
+            (s["SQ_INSTS_VALU"] / 1e6) if s else float("nan"),
+            (s.get("valu_busy_ms_at_2.4GHz", float("nan")) * 1e3) if s else float("nan")))
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    for tag in sys.argv[1:] or ["r3_c2", "r3_c4", "r3_c5"]:
+        text = table(tag)
+        with open(os.path.join(PROF, f"{tag}_kernel_table.txt"), "w") as f:
+            f.write(text)
+        print(text)
