@@ -408,7 +408,7 @@ def main():
         reducer.remove()                       # no collective may be launched from inside a capture:
                                                # replayed steps reduce with reducer.reduce_now()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        mode = "global" if world == 1 else "thread_local"   # other threads (RCCL watchdog) may
+        mode = "thread_local" if P.active(world) else "global"   # other threads (RCCL watchdog) may
         with torch.cuda.graph(ga, capture_error_mode=mode):  # call into the runtime meanwhile
             path_a().backward()
         with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
@@ -741,8 +741,8 @@ def main():
                     / (ms_a * 1e-3) / 1e12, 1),
             },
             "comm": {
-                "backend": (torch.distributed.get_backend() if world > 1 else None),
-                "world_size": world, "collective": "all_reduce(mean) of the path's parameter gradients, "
+                "backend": (torch.distributed.get_backend() if P.active(world) else None),
+                "world_size": world, "forced_one_rank_communicator": bool(world == 1 and P.active(world)), "collective": "all_reduce(mean) of the path's parameter gradients, "
                 "bucketed, asynchronous under the rasterizer backward (parallel.GradientReducer)",
                 "gradient_bytes_per_step": 4 * sum(p_.numel() for p_ in a_params),
                 "extra_payload_bytes_per_step": int(args.grad_payload_mb * 1e6),

@@ -26,14 +26,46 @@ def env_rank() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """Joins the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for 1 rank)."""
-    rank, world, local = env_rank()
+def force_comm() -> bool:
+    """PIXELSPLAT_FORCE_COMM=1: build the communicator, install the gradient hooks and launch the
+    collectives even for ONE rank.  A one-rank all-reduce changes no value, but it runs everything
+    else -- `init_process_group("nccl", device_id=...)`, the buckets' asynchronous collectives on
+    RCCL's own stream, their ordering against the compute stream, hipGraph capture and replay
+    beside a live communicator -- which is how the RCCL leg of the N-GPU path is executed on a
+    box with a single GPU (RCCL refuses two ranks on one device)."""
+    return os.environ.get("PIXELSPLAT_FORCE_COMM") == "1"
+
+
+def active(world: int) -> bool:
+    """Is there a communicator to talk to?  More than one rank, or a forced one-rank group."""
     if world > 1:
+        return True
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Joins the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for 1 rank unless
+    `force_comm()`)."""
+    rank, world, local = env_rank()
+    if world > 1 or force_comm():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:      # forced one-rank group without a launcher
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend is None:
             # PIXELSPLAT_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate
             # devices) -- how the N > 1 bench path is exercised on a single-GPU box
@@ -53,7 +85,7 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
 
 
 def barrier(world: int) -> None:
-    if world > 1:
+    if active(world):
         import torch.distributed as dist
 
         dist.barrier()
@@ -62,7 +94,7 @@ def barrier(world: int) -> None:
 
 
 def max_over_ranks(value: float, world: int, device: torch.device | str = "cpu") -> float:
-    if world <= 1:
+    if not active(world):
         return float(value)
     import torch.distributed as dist
 
@@ -73,7 +105,7 @@ def max_over_ranks(value: float, world: int, device: torch.device | str = "cpu")
 
 def gather_over_ranks(value: float, world: int, device: torch.device | str = "cpu") -> list[float]:
     """Every rank's value, in rank order (on every rank)."""
-    if world <= 1:
+    if not active(world):
         return [float(value)]
     import torch.distributed as dist
 
@@ -87,7 +119,7 @@ def comm_info(world: int, device: torch.device | str = "cpu") -> dict:
     """What the communicator actually is, for the bench line: backend, the number of ranks the
     collective library itself spans (checked by all-reducing a one per rank through it), the
     RCCL version torch was built against and the NCCL_* / RCCL_* knobs of the environment."""
-    info = dict(rccl_nranks=1 if world <= 1 else None, rccl_version=None, env={})
+    info = dict(rccl_nranks=None if active(world) else 1, rccl_version=None, env={})
     try:
         v = torch.cuda.nccl.version()
         info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
@@ -95,7 +127,7 @@ def comm_info(world: int, device: torch.device | str = "cpu") -> dict:
         pass
     info["env"] = {k: v for k, v in os.environ.items()
                    if k.startswith(("NCCL_", "RCCL_")) or k == "HSA_ENABLE_IPC_MODE_LEGACY"}
-    if world > 1:
+    if active(world):
         import torch.distributed as dist
 
         one = torch.ones(1, dtype=torch.float32, device=device)
@@ -116,7 +148,7 @@ def aggregate_throughput(units_per_rank_step: int, steps: int, world: int, elaps
 
 
 def shutdown(world: int) -> None:
-    if world > 1:
+    if active(world):
         import torch.distributed as dist
 
         dist.destroy_process_group()
@@ -127,13 +159,10 @@ def launch_ranks(n: int, script: str, argv: list[str], timeout: float | None = N
     launcher): the same command line `python -m torch.distributed.run --nnodes=1
     --nproc-per-node n --master-addr 127.0.0.1 --master-port P script argv` the driver uses,
     with a free port.  Returns the launcher's exit code; the ranks' stdout passes through."""
-    import socket
     import subprocess
     import sys
 
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
+    port = _free_port()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
@@ -163,7 +192,8 @@ class GradientReducer:
       `bucket_bytes` pieces (asynchronously, awaited by `finish()`): it models the gradients of
       the rest of the network (the reference reduces ~0.48 GB per step) when only
       the hot path's own parameters exist.
-    * world == 1: hooks are not installed, `finish()` is a no-op.
+    * world == 1: hooks are not installed, `finish()` is a no-op -- unless a one-rank communicator
+      was forced (`force_comm()`), in which case everything runs as for N ranks.
     """
 
     def __init__(self, params, world: int, bucket_bytes: int = 25 << 20, average: bool = True,
@@ -177,6 +207,7 @@ class GradientReducer:
         the hooks, under the rest of the backward, instead of waiting for `finish()` (DDP rebuilds
         its buckets after the first iteration for the same reason)."""
         self.world = world
+        self.active = active(world)
         self.average = average
         self.bucket_bytes = bucket_bytes
         self.params = [p for p in params if p.requires_grad]
@@ -192,7 +223,7 @@ class GradientReducer:
         self.extra_chunk = max(1, bucket_bytes // 4)
         self.stats = dict(buckets=0, bytes_per_step=0, launches=0, steps=0, launches_before_finish=0,
                           rebucketed=False)
-        if world <= 1:
+        if not self.active:
             return
         if device is None:
             device = self.params[0].device if self.params else (
@@ -251,7 +282,7 @@ class GradientReducer:
             (0 if self.extra is None else 4 * self.extra.numel())
 
     def install_hooks(self) -> None:
-        if self.world > 1 and not self._hooks:
+        if self.active and not self._hooks:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -308,7 +339,7 @@ class GradientReducer:
         means back into the gradient tensors.  Parameters without a gradient of their own -- None,
         or a tensor a previous `finish()` supplied because the parameter was unused on this rank
         -- count as zero."""
-        if self.world <= 1 or not self.params:
+        if not self.active or not self.params:
             return
         for b in self.buckets:
             if b["launched"]:
@@ -328,7 +359,7 @@ class GradientReducer:
     def launch_extra_payload(self) -> None:
         """All-reduce of the synthetic payload (the rest of the network's gradients), in
         bucket-sized pieces, asynchronously; call where that backward would run."""
-        if self.world <= 1 or self.extra is None:
+        if not self.active or self.extra is None:
             return
         import torch.distributed as dist
 
@@ -341,7 +372,7 @@ class GradientReducer:
     def finish(self) -> None:
         """End of the step: reduce what is still incomplete (unused parameters count as zero),
         wait for every collective, re-arm."""
-        if self.world <= 1:
+        if not self.active:
             return
         for b in self.buckets:
             if not b["launched"]:

@@ -248,3 +248,57 @@ def test_four_ranks_uneven_times_and_reducer_edge_cases():
         assert r["value"] == world * 28 / max(times)        # NOT the mean of per-rank rates
         assert r["comm"]["rccl_nranks"] == world
         assert len(r["exposed"]) == 3 and all(e >= 0 for e in r["exposed"])
+
+
+# ---- forced one-rank communicator (PIXELSPLAT_FORCE_COMM=1) ------------------------------
+def _forced_worker(rank, world, port, out):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    os.environ.update(PIXELSPLAT_FORCE_COMM="1", PIXELSPLAT_DIST_BACKEND="gloo")
+    from pixelsplat_amd import parallel as P
+
+    r, w, _ = P.init_from_env()
+    assert (r, w) == (0, 1) and P.active(w) and P.force_comm()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3),
+                              torch.nn.Linear(3, 3))        # the last layer stays unused
+    x = torch.randn(7, 6)
+    ref = [g.clone() for g in torch.autograd.grad(net[:3](x).square().sum(), list(net[:3].parameters()))]
+    red = P.GradientReducer(list(net.parameters()), w, bucket_bytes=64, extra_payload_bytes=1024)
+    assert red.active and red.stats["buckets"] > 1
+    for _ in range(2):                                       # step 2 runs on the re-bucketed layout
+        for p in net.parameters():
+            p.grad = None
+        net[:3](x).square().sum().backward()
+        red.launch_extra_payload()
+        red.finish()
+        got = [p.grad.clone() for p in net[:3].parameters()]
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))          # mean over one rank
+        assert all(float(p.grad.abs().max()) == 0.0 for p in net[3].parameters())
+    launches_hooks = red.stats["launches"]
+    red.remove()                                             # hook-free variant (graph replays)
+    for p, g in zip(net[:3].parameters(), ref):
+        p.grad = g.clone()
+    red.reduce_now()
+    red.finish()
+    assert all(torch.equal(p.grad, g) for p, g in zip(net[:3].parameters(), ref))
+    info = P.comm_info(w)
+    out["res"] = (red.stats["steps"], launches_hooks, red.stats["launches"], red.stats["rebucketed"],
+                  info["rccl_nranks"], P.max_over_ranks(2.5, w), P.gather_over_ranks(1.5, w),
+                  len(red.exposed_ms()))
+    P.barrier(w)
+    P.shutdown(w)
+    assert not P.active(w)
+
+
+def test_forced_one_rank_communicator_runs_the_whole_reducer():
+    """PIXELSPLAT_FORCE_COMM=1: a single rank builds a real process group, the hooks launch real
+    collectives and the values do not change -- the mode the RCCL leg is run in on a one-GPU box
+    (tests/test_rccl_one_rank_gpu.py)."""
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_forced_worker, args=(1, 0, out), nprocs=1, join=True)
+        steps, l_hooks, l_all, rebucketed, nranks, mx, gathered, n_exposed = out["res"]
+    assert steps == 3 and rebucketed and nranks == 1
+    assert l_hooks > 0 and l_all > l_hooks and n_exposed == 3
+    assert mx == 2.5 and gathered == [1.5]
