@@ -299,6 +299,12 @@ def main():
         # `python bench.py --gpus N` without a launcher: become N ranks of this node (the same
         # torch.distributed.run command line the driver uses), one process per GPU over RCCL
         sys.exit(P.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    # stdout carries the ONE JSON line and nothing else: native libraries write to file descriptor 1
+    # behind Python's back (RCCL prints a three-line version banner when a communicator is built), so
+    # fd 1 is pointed at stderr for the run and the line goes to a private duplicate of the real one
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank, world, local = P.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s); "
@@ -805,7 +811,8 @@ def main():
                              f"({b} x scene time + {V} x view time)")
             out["cpu_baseline"] = cb
             out["parity_vs_oracle"] = parity
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     P.shutdown(world)
 
 

@@ -344,13 +344,21 @@ class GradientReducer:
         for b in self.buckets:
             if b["launched"]:
                 raise RuntimeError("GradientReducer.reduce_now(): the previous step was not finished")
+            dst, src, zero = [], [], []
             for slot, (p, view) in enumerate(zip(b["params"], b["views"])):
                 own = p.grad is not None and id(p) not in self._given
                 if not own:
-                    view.zero_()
+                    zero.append(view)
                 elif p.grad.data_ptr() != view.data_ptr():
-                    view.copy_(p.grad)
+                    dst.append(view)
+                    src.append(p.grad)
                 b["ready"][slot] = own
+            # one multi-tensor launch per bucket instead of one copy per parameter (62 parameters
+            # on path (A): the per-tensor copies were most of what the reducer added to a step)
+            if zero:
+                torch._foreach_zero_(zero)
+            if dst:
+                torch._foreach_copy_(dst, src)
             b["pending"] = 0
             b["copy_back"] = True
             self._launch(b)
@@ -401,9 +409,13 @@ class GradientReducer:
         self._works.clear()
         for b in self.buckets:
             if b.pop("copy_back", False):      # reduce_now(): static gradient tensors keep their
-                for p, view, ok in zip(b["params"], b["views"], b["ready"]):   # storage: copy back
+                dst, src = [], []              # storage: copy back (one multi-tensor launch)
+                for p, view, ok in zip(b["params"], b["views"], b["ready"]):
                     if ok and p.grad.data_ptr() != view.data_ptr():
-                        p.grad.copy_(view)
+                        dst.append(p.grad)
+                        src.append(view)
+                if dst:
+                    torch._foreach_copy_(dst, src)
             # a parameter unused on THIS rank still receives the other ranks' mean gradient
             for p, view, ok in zip(b["params"], b["views"], b["ready"]):
                 if not ok:

@@ -23,8 +23,8 @@ def _bench(*extra):
            "--size", "64", "--batch", "1", "--no-cpu-baseline", "--no-probes", *extra]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 alone prints the line
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 alone prints the line, nothing else does
     return json.loads(lines[0])
 
 
