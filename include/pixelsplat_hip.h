@@ -60,8 +60,10 @@ typedef enum PsStatus {
                                       1.0 for the plain per-view boundary)            */
 
 /* PsRasterDesc.flags: the caller has already zeroed the backward temp buffer with
- * ps_raster_backward_prepare (e.g. on a second stream while the forward's tile kernels, which
- * are VALU-bound, run), so ps_raster_backward skips its own memset. */
+ * ps_raster_backward_prepare, so ps_raster_backward skips its own clearing.  Since round 3 that
+ * clearing is a 10 us kernel over the accumulator rows actually in use (pairs covering more than
+ * four tiles) instead of a memset of the whole buffer: neither the flag nor the prepare call buys
+ * anything any more; both are kept so that existing hosts keep working. */
 #define PS_FLAG_BWD_TEMP_ZEROED 1
 /* ps_raster_forward_plan leaves the SH -> RGB evaluation to a later ps_raster_forward_colors
  * (any time before ps_raster_forward_tiles): a host that reads D back after the plan can queue
@@ -152,8 +154,7 @@ int ps_raster_forward_render(const PsRasterDesc* desc, const float* view_params,
                              size_t temp_bytes, uint32_t* point_list, size_t list_capacity,
                              void* stream);
 /* ps_raster_forward_render in its two halves (tile lists, then blending), for hosts that want
- * to put other work between them -- e.g. ps_raster_backward_prepare on a second stream once
- * the memory-bound list write is done, under the VALU-bound blend. */
+ * to put other work between them. */
 int ps_raster_forward_colors(const PsRasterDesc* desc, const float* means, const float* sh,
                              const float* view_params, const int32_t* radii, void* state,
                              size_t state_bytes, void* temp, size_t temp_bytes, void* stream);
@@ -191,9 +192,10 @@ int ps_raster_backward(const PsRasterDesc* desc, const float* means, const float
 int ps_raster_check(const PsRasterDesc* desc, const void* state, size_t state_bytes,
                     uint64_t* num_rendered, void* stream);
 
-/* Zeroes the backward temp buffer (the accumulators ps_raster_backward expects cleared).  Issue
- * it any time after list_capacity is known and before ps_raster_backward, on any stream; then
- * set PS_FLAG_BWD_TEMP_ZEROED in the descriptor handed to ps_raster_backward. */
+/* Zeroes the backward temp buffer's accumulators (all of them).  Optional since round 3 --
+ * ps_raster_backward clears what it needs itself (see PS_FLAG_BWD_TEMP_ZEROED).  Issue it any time
+ * after list_capacity is known and before ps_raster_backward, on any stream; then set
+ * PS_FLAG_BWD_TEMP_ZEROED in the descriptor handed to ps_raster_backward. */
 int ps_raster_backward_prepare(const PsRasterDesc* desc, void* temp, size_t temp_bytes,
                                size_t list_capacity, void* stream);
 

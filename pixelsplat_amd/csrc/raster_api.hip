@@ -288,8 +288,9 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   float* tile_grads = (float*)(tb + T.tile_grads);
   if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
     Scope sc(G_MEMSET, st);
-    // one memset covers grad2d (atomic path) and the per-(tile, entry) slots
-    if (hipMemsetAsync(tb, 0, T.zeroed, st) != hipSuccess) return PS_ERR_LAUNCH;
+    // only the grad2d rows the tile backward adds into with atomics (pairs over > kInvSlots
+    // tiles); the private slots are written exactly once each and need no clearing
+    launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
   }
   {
     Scope sc(G_TILES_BWD, st);

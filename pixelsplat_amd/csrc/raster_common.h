@@ -72,7 +72,8 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
   return t;
 }
 
-// grad2d and tile_grads are accumulators (zeroed: bytes [0, zeroed)); color_grads is the compact
+// grad2d is the atomic accumulator of the pairs with > kInvSlots tiles (bytes [0, zeroed): ps_raster_backward
+// clears the rows in use itself, ps_raster_backward_prepare clears all of it); color_grads is the compact
 // per-(view, Gaussian) dL/dRGB the geometry backward hands to the SH backward (12 B rows
 // instead of 3 floats out of every 36-byte grad2d row and 1 out of every 48-byte record)
 struct BwdTempLayout { size_t grad2d, tile_grads, zeroed, color_grads, total; };
@@ -143,6 +144,8 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            const float* dL_dcolor, float* grad2d, float* tile_grads,
                            hipStream_t st);
 
+void launch_clear_atomic_rows(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
+                              float* grad2d, hipStream_t st);
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,

@@ -105,7 +105,6 @@ class ForwardResult:
     num_rendered: int | None  # D when it was read back (exact-size mode), else None
     overflow_host: Tensor | None = None
     overflow_event: object | None = None
-    bwd_temp: tuple | None = None  # (zeroed backward temp buffer, its event) when grads are wanted
 
     def check_overflow(self, capacity: int) -> None:
         """Fixed-capacity mode: waits for the forward's 8-byte flag copy and raises when the
@@ -121,8 +120,7 @@ class ForwardResult:
                 f"(exact sizing)")
 
 
-def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
-             want_backward: bool = False) -> ForwardResult:
+def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params) -> ForwardResult:
     lib = _lib.load()
     d = cfg.desc()
     V, dev = cfg.n_views, means.device
@@ -139,7 +137,6 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
         _lib.check(lib.ps_raster_forward_bins(
             C.byref(d), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist), plist.numel(),
             _stream()), "ps_raster_forward_bins")
-        bwd_temp = _zeroed_backward_temp(cfg, plist.numel(), dev) if want_backward else None
         _lib.check(lib.ps_raster_forward_tiles(
             C.byref(d), _p(view_params), _p(color), _p(state), state.numel(), _p(temp),
             temp.numel(), _p(plist), plist.numel(), _stream()), "ps_raster_forward_tiles")
@@ -156,7 +153,7 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
         else:
             ev = torch.cuda.Event()
             ev.record()
-        return ForwardResult(color, radii, state, plist, None, flag, ev, bwd_temp)
+        return ForwardResult(color, radii, state, plist, None, flag, ev)
     # exact sizing: D is read back once per batch.  The SH colours are deferred behind that
     # copy, so the GPU evaluates them while the host waits for D, allocates and launches.
     _defer = sh is not None
@@ -182,17 +179,12 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params,
     _lib.check(lib.ps_raster_forward_bins(
         C.byref(d), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist), int(n.value),
         _stream()), "ps_raster_forward_bins")
-    # the backward's accumulators are cleared HERE, on a second stream: the memset (~1 GB at
-    # configs[1]) runs under the VALU-bound blend instead of in front of the backward's (under
-    # the memory-bound list write it only slowed that one down)
-    bwd_temp = _zeroed_backward_temp(cfg, plist.numel(), dev) if want_backward else None
     _lib.check(lib.ps_raster_forward_tiles(
         C.byref(d), _p(view_params), _p(color), _p(state), state.numel(), _p(temp), temp.numel(),
         _p(plist), int(n.value), _stream()), "ps_raster_forward_tiles")
-    return ForwardResult(color, radii, state, plist, int(n.value), bwd_temp=bwd_temp)
+    return ForwardResult(color, radii, state, plist, int(n.value))
 
 
-_SIDE_STREAMS: dict = {}
 _CAPTURE_FREE: list = []      # pinned buffers reserved for forwards recorded into a hipGraph
 _CAPTURED_FLAGS: list = []    # (flag, capacity) of forwards recorded into a hipGraph
 _CAPTURE_RESERVE = 32
@@ -244,27 +236,6 @@ def captured_overflow_flags(check: bool = True) -> list:
     return out
 
 
-def _zeroed_backward_temp(cfg: "RasterConfig", capacity: int, dev):
-    """(temp buffer of ps_raster_backward, event after its ps_raster_backward_prepare)."""
-    lib = _lib.load()
-    d = cfg.desc()
-    temp = torch.empty(lib.ps_raster_backward_temp_bytes(C.byref(d), capacity), dtype=torch.uint8,
-                       device=dev)
-    main = torch.cuda.current_stream()
-    side = _SIDE_STREAMS.get(dev)
-    if side is None:
-        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    side.wait_stream(main)          # the allocator may hand out memory still in use upstream
-    temp.record_stream(side)
-    with torch.cuda.stream(side):
-        _lib.check(lib.ps_raster_backward_prepare(C.byref(d), _p(temp), temp.numel(), capacity,
-                                                  C.c_void_p(side.cuda_stream)),
-                   "ps_raster_backward_prepare")
-        zeroed = torch.cuda.Event()
-        zeroed.record(side)
-    return temp, zeroed
-
-
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: RasterConfig, means, cov, opacity, sh, colors, view_params, means2d):
@@ -273,13 +244,11 @@ class _Rasterize(torch.autograd.Function):
         sh = None if sh is None else sh.contiguous()
         colors = None if colors is None else colors.contiguous()
         view_params = view_params.contiguous()
-        r = _forward(cfg, means, cov, opacity, sh, colors, view_params,
-                     want_backward=any(ctx.needs_input_grad))
+        r = _forward(cfg, means, cov, opacity, sh, colors, view_params)
         if not any(ctx.needs_input_grad):
             # inference (no backward will ever read the flag): check the capacity now, one
             # host wait on an 8-byte copy that was queued right behind the forward
             r.check_overflow(cfg.list_capacity)
-        ctx.bwd_temp = r.bwd_temp
         ctx.cfg = cfg
         ctx.has_means2d = means2d is not None
         ctx.overflow = (r.overflow_host, r.overflow_event)
@@ -306,14 +275,10 @@ class _Rasterize(torch.autograd.Function):
         g_colors = torch.empty_like(colors) if colors is not None else None
         g_m2d = (torch.empty((V, cfg.n_gaussians, 3), dtype=torch.float32, device=dev)
                  if ctx.has_means2d else None)
-        if ctx.bwd_temp is not None:
-            temp, zeroed = ctx.bwd_temp
-            ctx.bwd_temp = None
-            torch.cuda.current_stream().wait_event(zeroed)
-            d.flags |= _lib.PS_FLAG_BWD_TEMP_ZEROED
-        else:
-            temp = torch.empty(lib.ps_raster_backward_temp_bytes(C.byref(d), plist.numel()),
-                               dtype=torch.uint8, device=dev)
+        # no memset: ps_raster_backward clears the few accumulator rows it adds into by itself
+        # (round 3; a whole-buffer memset on a second stream under the forward cost the step 0.11 ms)
+        temp = torch.empty(lib.ps_raster_backward_temp_bytes(C.byref(d), plist.numel()),
+                           dtype=torch.uint8, device=dev)
         _lib.check(lib.ps_raster_backward(
             C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
             _p(radii), _p(dL_dcolor), _p(state), state.numel(), _p(temp), temp.numel(),

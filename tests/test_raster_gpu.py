@@ -322,6 +322,40 @@ def test_one_call_abi_equals_the_split_calls(gpu_device):
                "ps_raster_forward")
     assert torch.equal(color, img_a) and torch.equal(radii, radii_a)
 
+    # the backward of the raw ABI on a temp buffer full of garbage: ps_raster_backward clears the
+    # accumulator rows it adds into by itself (pairs over more than four tiles take the atomic path;
+    # the workload must contain some), and the optional prepare + PS_FLAG_BWD_TEMP_ZEROED route of
+    # older hosts still gives the same gradients
+    lay = _lib.PsRasterStateLayout()
+    lib.ps_raster_state_layout(C.byref(d), C.byref(lay))
+    rc = state[lay.rects:lay.rects + 8 * radii.numel()].view(torch.int32).view(-1, 2).cpu().numpy().astype(np.int64)
+    area = ((rc[:, 1] & 0xFFFF) - (rc[:, 0] & 0xFFFF)) * ((rc[:, 1] >> 16) - (rc[:, 0] >> 16))
+    n_atomic = int(((area > 4) & (radii.cpu().numpy().reshape(-1) > 0)).sum())
+    assert n_atomic > 0, "no Gaussian over more than four tiles: the atomic path is not exercised"
+    dL = torch.linspace(0.5, 1.5, img_a.numel(), device=dev).view_as(img_a).contiguous()
+
+    def raw_backward(prepare):
+        db = cfg.desc()
+        tb = torch.empty(lib.ps_raster_backward_temp_bytes(C.byref(db), plist.numel()), dtype=torch.uint8,
+                         device=dev)
+        tb.view(torch.float32)[: tb.numel() // 4].fill_(float("nan"))
+        if prepare:
+            _lib.check(lib.ps_raster_backward_prepare(C.byref(db), _p(tb), tb.numel(), plist.numel(),
+                                                      _stream()), "ps_raster_backward_prepare")
+            db.flags |= _lib.PS_FLAG_BWD_TEMP_ZEROED
+        outs = [torch.full_like(t, float("nan")) for t in (means, cov, sh, op)]
+        _lib.check(lib.ps_raster_backward(
+            C.byref(db), _p(means), _p(cov), _p(sh), None, _p(op), _p(vp), _p(radii), _p(dL), _p(state),
+            state.numel(), _p(tb), tb.numel(), _p(plist), plist.numel(), _p(outs[0]), _p(outs[1]),
+            _p(outs[2]), None, _p(outs[3]), None, _stream()), "ps_raster_backward")
+        return outs
+
+    for prepare in (False, True):
+        g_means, g_cov, g_sh, g_op = raw_backward(prepare)
+        for got, want in zip((g_means, g_cov, g_op, g_sh), grads_a):
+            assert bool(torch.isfinite(got).all())
+            torch.testing.assert_close(got, want.view_as(got), rtol=1e-5, atol=1e-7)
+
 
 @pytest.mark.parametrize("seed,n,hw", [(11, 600, (64, 64)), (12, 1500, (96, 80))])
 def test_opaque_front_layer_and_never_blended_tail(gpu_device, seed, n, hw):
