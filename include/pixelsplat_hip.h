@@ -61,7 +61,7 @@ typedef enum PsStatus {
 
 /* PsRasterDesc.flags: the caller has already zeroed the backward temp buffer with
  * ps_raster_backward_prepare, so ps_raster_backward skips its own clearing.  Since round 3 that
- * clearing is a 10 us kernel over the accumulator rows actually in use (pairs covering more than
+ * clearing is a 30 us kernel over the accumulator rows actually in use (pairs covering more than
  * four tiles) instead of a memset of the whole buffer: neither the flag nor the prepare call buys
  * anything any more; both are kept so that existing hosts keep working. */
 #define PS_FLAG_BWD_TEMP_ZEROED 1

@@ -344,17 +344,17 @@ color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
 // Rows of grad2d the tile backward accumulates into with atomics: visible pairs whose rect covers
 // more than kInvSlots tiles -- the predicate of packed_small_rect (raster_preprocess.hip) and of the
 // slot branch of geometry_backward_kernel above, which reads exactly these rows.  Clearing only
-// them replaces a memset of the whole [V, G, 9] array: 132 MB at configs[1], a 0.16 - 0.19 ms fill
+// them replaces a memset of the whole [V, G, 9] array: 396 MB at configs[1], a 0.16 - 0.19 ms fill
 // kernel that took 0.11 ms out of the step even on a second stream under the forward.
 __global__ void __launch_bounds__(256)
 clear_atomic_rows_kernel(size_t n, int tiles_y, const int32_t* __restrict__ radii,
                          const uint2* __restrict__ rects, float* __restrict__ grad2d) {
   const size_t vg = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (vg >= n) return;
-  const int32_t rad = radii[vg];
+  if (radii[vg] <= 0) return;           // culled pairs (60 % at configs[1]) never read their rect
   const uint2 r = rects[vg];
   const uint32_t area = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
-  if (rad <= 0 || (area <= (uint32_t)kInvSlots && tiles_y <= 16383)) return;
+  if (area <= (uint32_t)kInvSlots && tiles_y <= 16383) return;
   float* g = grad2d + vg * kGradFloats;
 #pragma unroll
   for (int c = 0; c < kGradFloats; ++c) g[c] = 0.f;
