@@ -2,11 +2,12 @@
 
 Same public surface: attributes num_samples / index_v / transpose_v / transpose_ov
 (non-persistent buffers), methods forward / generate_image_rays / transpose / collect, return
-type EpipolarSampling with the same eight fields.  forward() is one HIP launch for the whole
+type EpipolarSampling with the same eight fields (`features` gathered on first access when the
+fused path did not need it).  forward() is one HIP launch for the whole
 geometry (ps_epipolar_geometry) plus one for the feature gather (ps_epipolar_gather)."""
 from __future__ import annotations
 
-from dataclasses import dataclass
+from typing import Callable
 
 import torch
 from torch import Tensor, nn
@@ -14,16 +15,48 @@ from torch import Tensor, nn
 from ..epipolar import EpipolarGeometry, gather_features, sample_geometry
 
 
-@dataclass
 class EpipolarSampling:
-    features: Tensor | None    # [batch, view, other_view, ray, sample, channel]
-    valid: Tensor              # [batch, view, other_view, ray] bool
-    xy_ray: Tensor             # [batch, view, ray, 2]
-    xy_sample: Tensor          # [batch, view, other_view, ray, sample, 2]
-    xy_sample_near: Tensor
-    xy_sample_far: Tensor
-    origins: Tensor            # [batch, view, ray, 3]
-    directions: Tensor         # [batch, view, ray, 3]
+    """The reference's record of eight tensors (epipolar_sampler.py:19-29), same names, same constructor
+    keywords.  `features` is the one tensor the fused path never needs (0.94 GB at the paper shape): when
+    the producer did not materialise it, it is gathered on FIRST ACCESS from the feature map the sampling
+    was made from (`lazy_features`) -- a consumer such as the reference's visualiser, which reads
+    `sampling.features` out of the `visualization_dump`, gets the tensor either way and the training step
+    never pays for it."""
+    FIELDS = ("features", "valid", "xy_ray", "xy_sample", "xy_sample_near", "xy_sample_far", "origins",
+              "directions")
+
+    def __init__(self, features: Tensor | None, valid: Tensor, xy_ray: Tensor, xy_sample: Tensor,
+                 xy_sample_near: Tensor, xy_sample_far: Tensor, origins: Tensor, directions: Tensor,
+                 lazy_features: Callable[[], Tensor] | None = None) -> None:
+        self._features = features            # [batch, view, other_view, ray, sample, channel] | None
+        self._lazy = lazy_features if features is None else None
+        self.valid = valid                    # [batch, view, other_view, ray] bool
+        self.xy_ray = xy_ray                  # [batch, view, ray, 2]
+        self.xy_sample = xy_sample            # [batch, view, other_view, ray, sample, 2]
+        self.xy_sample_near = xy_sample_near
+        self.xy_sample_far = xy_sample_far
+        self.origins = origins                # [batch, view, ray, 3]
+        self.directions = directions          # [batch, view, ray, 3]
+
+    @property
+    def features(self) -> Tensor | None:
+        if self._features is None and self._lazy is not None:
+            self._features, self._lazy = self._lazy(), None
+        return self._features
+
+    @features.setter
+    def features(self, value: Tensor | None) -> None:
+        self._features, self._lazy = value, None
+
+    @property
+    def features_materialized(self) -> bool:
+        return self._features is not None
+
+    def __repr__(self) -> str:
+        shapes = {k: (tuple(getattr(self, k).shape) if k != "features" else
+                      (tuple(self._features.shape) if self._features is not None else
+                       ("lazy" if self._lazy is not None else None))) for k in self.FIELDS}
+        return f"EpipolarSampling({shapes})"
 
 
 def heterogeneous_index(n: int) -> tuple[Tensor, Tensor]:
@@ -65,7 +98,9 @@ class EpipolarSampler(nn.Module):
         return sample_geometry(extrinsics, intrinsics, near, far, grid_hw, self.num_samples)
 
     def sampling_from_geometry(self, geo: EpipolarGeometry, grid_hw: tuple[int, int],
-                               features: Tensor | None) -> EpipolarSampling:
+                               features: Tensor | None, fmap: Tensor | None = None) -> EpipolarSampling:
+        """`features` None + `fmap` (channels-last feature map): the gather is deferred to the first
+        read of `.features` (on a detached map: it is a visualisation product, not part of the graph)."""
         h, w = grid_hw
         b, v = geo.origins.shape[:2]
         s = self.num_samples
@@ -79,11 +114,15 @@ class EpipolarSampler(nn.Module):
         depth = ((torch.arange(s, device=dev) + 0.5) / s)[:, None]
         half = 0.5 / s
         a, d_ = xy_min[..., None, :], (xy_max - xy_min)[..., None, :]
+        lazy = None
+        if features is None and fmap is not None:
+            src = fmap.detach()
+            lazy = lambda: gather_features(src, geo)  # noqa: E731
         return EpipolarSampling(
             features=features, valid=geo.overlaps, xy_ray=xy.expand(b, v, h * w, 2),
             xy_sample=geo.xy_sample, xy_sample_near=a + (depth - half) * d_,
             xy_sample_far=a + (depth + half) * d_, origins=geo.origins,
-            directions=geo.directions)
+            directions=geo.directions, lazy_features=lazy)
 
     def forward(self, images: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                 far: Tensor) -> EpipolarSampling:

@@ -236,7 +236,7 @@ class EpipolarTransformer(nn.Module):
         hooked = any(len(layer[0].fn.attend._forward_hooks) > 0 for layer in self.transformer.layers)
         need_kv = hooked or materialize_sampling
         sampled = gather_features(fmap, geo) if need_kv else None
-        sampling = sampler.sampling_from_geometry(geo, (h, w), sampled)
+        sampling = sampler.sampling_from_geometry(geo, (h, w), sampled, fmap)   # .features: lazy if None
 
         x = fmap.reshape(b * v * h * w, 1, c)
         kv = None

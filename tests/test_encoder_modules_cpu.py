@@ -103,3 +103,30 @@ def test_fold_attention_weights_algebra():
                 ctxv = ctxv + ve.T @ ab[h]
             ref += wo.reshape(d_out, H, dh)[:, h] @ (wv[h] @ ctxv)
         assert torch.allclose(fused @ w_o_t + bias, ref, atol=1e-3)
+
+
+def test_sampling_features_are_gathered_on_first_access():
+    """EpipolarSampling keeps the reference's constructor and attribute names; `features` left out by the
+    fused path is produced once, on first read, by the deferred gather."""
+    from pixelsplat_amd.encoder import EpipolarSampling
+
+    z = torch.zeros(1)
+    calls = []
+
+    def gather():
+        calls.append(1)
+        return torch.full((2, 3), 7.0)
+
+    s = EpipolarSampling(features=None, valid=z, xy_ray=z, xy_sample=z, xy_sample_near=z, xy_sample_far=z,
+                         origins=z, directions=z, lazy_features=gather)
+    assert not s.features_materialized and "lazy" in repr(s) and calls == []
+    f = s.features
+    assert f.shape == (2, 3) and s.features is f and calls == [1] and s.features_materialized
+    eager = EpipolarSampling(torch.ones(4), z, z, z, z, z, z, z, lazy_features=gather)
+    assert eager.features.shape == (4,) and calls == [1]          # a given tensor wins, no gather
+    none = EpipolarSampling(None, z, z, z, z, z, z, z)
+    assert none.features is None
+    none.features = torch.ones(2)
+    assert none.features.shape == (2,)
+    assert set(EpipolarSampling.FIELDS) == {"features", "valid", "xy_ray", "xy_sample", "xy_sample_near",
+                                            "xy_sample_far", "origins", "directions"}

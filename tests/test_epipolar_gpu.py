@@ -308,6 +308,13 @@ def test_epipolar_transformer_module_vs_reference_golden(gpu_device, name, v, oc
     assert (samp.xy_sample_far.cpu() - g["xy_sample_far"]).abs().max() < 1e-5
     assert torch.equal(samp.xy_ray.cpu(), g["xy_ray"])
     assert (samp.features.cpu() - g["sampled"]).abs().max() < 1e-4
+    # as the reference's EncoderEpipolar calls it (no materialize_sampling, no hooks): the fused path
+    # does not build the sampled features, a reader of `sampling.features` (the visualiser, through the
+    # visualization_dump) gets them on first access -- the same bits
+    out_l, samp_l = net(*args, view_shuffle=g["shuffle"].to(dev) if v > 2 else None)
+    assert torch.equal(out_l, out) and not samp_l.features_materialized
+    assert torch.equal(samp_l.features, samp.features) and samp_l.features_materialized
+    assert not samp_l.features.requires_grad
     scale = g["out"].abs().max().item()
     assert (out.cpu() - g["out"]).abs().max() < 5e-3 * max(scale, 1.0)
     # the hooked (unfused) fallback gives the same result and exposes the attention weights
