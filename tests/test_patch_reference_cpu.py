@@ -107,3 +107,78 @@ def test_switch_off(live_reference, monkeypatch):
     assert pr.apply() == {"*": "disabled by PIXELSPLAT_HIP=0"}
     dec_pkg = importlib.import_module("src.model.decoder")
     assert dec_pkg.DECODERS["splatting_cuda"].__module__ == "src.model.decoder.decoder_splatting_cuda"
+
+
+def _calls_on(path, attr_names):
+    """Every call `self.<attr>(...)`, `self.<attr>.<method>(...)` or `<attr>.<method>(...)` in a
+    reference source file -> [(attr, method | None, n_positional, [keyword names], lineno)]."""
+    import ast
+
+    found = []
+    for node in ast.walk(ast.parse(open(path).read())):
+        if not isinstance(node, ast.Call):
+            continue
+        f, method = node.func, None
+        if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Attribute) and f.value.attr in attr_names:
+            f, method = f.value, f.attr                      # self.decoder.forward(...)
+        elif isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in attr_names:
+            found.append((f.value.id, f.attr, len(node.args), [k.arg for k in node.keywords], node.lineno))
+            continue                                         # loss_fn.forward(...)
+        if isinstance(f, ast.Attribute) and f.attr in attr_names and isinstance(f.value, ast.Name) \
+                and f.value.id == "self":
+            found.append((f.attr, method, len(node.args), [k.arg for k in node.keywords], node.lineno))
+    return found
+
+
+def test_every_reference_call_site_binds_to_the_drop_in_signatures(live_reference):
+    """The glue nobody can run end to end (the reference is not on the GPU box, the GPU is not here):
+    every call the reference makes into a swapped module -- encoder_epipolar.py:130-172 into the
+    transformer, the depth predictor and the adapter; model_wrapper.py into the decoder and the losses --
+    must bind to the drop-in's signature, by position and by keyword, and the constructors must take
+    what the reference passes (encoder_epipolar.py:66-78)."""
+    import inspect
+
+    from pixelsplat_amd import decoder as our_decoder
+    from pixelsplat_amd import encoder as our_encoder
+    from pixelsplat_amd import loss as our_loss
+
+    ref = RI.REF
+    enc_calls = _calls_on(os.path.join(ref, "src/model/encoder/encoder_epipolar.py"),
+                          {"epipolar_transformer", "depth_predictor", "gaussian_adapter"})
+    mw_calls = _calls_on(os.path.join(ref, "src/model/model_wrapper.py"), {"decoder", "loss_fn"})
+    owners = {"epipolar_transformer": our_encoder.EpipolarTransformer,
+              "depth_predictor": our_encoder.DepthPredictorMonocular,
+              "gaussian_adapter": our_encoder.GaussianAdapter,
+              "decoder": our_decoder.DecoderSplattingCUDA}
+    checked = 0
+    for attr, method, n_pos, kw, line in enc_calls + mw_calls:
+        if method in ("d_in", "d_sh") or (method is None and attr == "gaussian_adapter"):
+            continue
+        targets = [owners[attr]] if attr in owners else [our_loss.LossMse, our_loss.LossDepth]
+        for cls in targets:
+            fn = getattr(cls, method or "forward")
+            try:
+                inspect.signature(fn).bind(object(), *([object()] * n_pos), **{k: object() for k in kw})
+            except TypeError as err:
+                raise AssertionError(f"{attr}.{method or '__call__'} at line {line} does not bind to "
+                                     f"{cls.__module__}.{cls.__name__}: {err}") from None
+            checked += 1
+    assert checked >= 8, (enc_calls, mw_calls)
+
+    # forward / constructor parameter names of the reference classes are a positional prefix of ours
+    ref_enc = importlib.import_module("src.model.encoder.encoder_epipolar")
+    ref_dec = importlib.import_module("src.model.decoder.decoder_splatting_cuda")
+    pairs = [(ref_enc.EpipolarTransformer, our_encoder.EpipolarTransformer),
+             (ref_enc.DepthPredictorMonocular, our_encoder.DepthPredictorMonocular),
+             (ref_enc.GaussianAdapter, our_encoder.GaussianAdapter),
+             (ref_dec.DecoderSplattingCUDA, our_decoder.DecoderSplattingCUDA),
+             (importlib.import_module("src.loss.loss_mse").LossMse, our_loss.LossMse),
+             (importlib.import_module("src.loss.loss_depth").LossDepth, our_loss.LossDepth)]
+    for ref_cls, our_cls in pairs:
+        for name in ("__init__", "forward"):
+            want = list(inspect.signature(getattr(ref_cls, name)).parameters)
+            got = list(inspect.signature(getattr(our_cls, name)).parameters)
+            assert got[:len(want)] == want, f"{our_cls.__name__}.{name}: {got} vs reference {want}"
+            extra = list(inspect.signature(getattr(our_cls, name)).parameters.values())[len(want):]
+            assert all(p.default is not inspect.Parameter.empty or p.kind in
+                       (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in extra), f"{our_cls.__name__}.{name}: {extra}"
