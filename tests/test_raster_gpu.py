@@ -270,8 +270,8 @@ def test_camera_setup_matches_reference_host_math(gpu_device):
 
 
 def test_one_call_abi_equals_the_split_calls(gpu_device):
-    """ps_raster_forward (plan + render in one call, in-line memset in the backward) against the
-    host path's plan / deferred colours / bins / side-stream memset / tiles sequence, and the
+    """ps_raster_forward (plan + render in one call) against the host path's plan / deferred
+    colours / bins / tiles sequence, the raw backward on a garbage-filled temp buffer, and the
     fixed-capacity mode against exact sizing: identical bits for images, radii and gradients
     of the slot (deterministic) path."""
     import ctypes as C
