@@ -394,15 +394,13 @@ def main():
 
     graphs = {}
 
-    def capture_graphs():
-        """The step as two hipGraphs -- (A) forward + backward, (B) forward + backward -- sharing
-        one memory pool.  ~95 launches of (A) and ~30 of (B) become two graph launches: no
-        per-launch host cost, no allocator traffic, no host synchronisation (fixed-capacity tile
-        lists; an overflow is read back after the replay).  The gradient all-reduce is launched
-        between the two replays, so it runs under (B) exactly as in the eager schedule."""
+    def capture_warm_up():
+        """Eager warm-up on the stream mode that will be captured.  Contains the reducer's collectives:
+        a rank that fails in here cannot be waited for by its peers -- the caller aborts the
+        job for N > 1 instead of falling back."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # eager warm-up in the mode that will be captured
+        with torch.cuda.stream(side):
             for _ in range(2):
                 zero_grads()
                 path_a().backward()
@@ -413,6 +411,14 @@ def main():
         zero_grads()
         reducer.remove()                       # no collective may be launched from inside a capture:
                                                # replayed steps reduce with reducer.reduce_now()
+
+    def capture_graphs():
+        """The step as two hipGraphs -- (A) forward + backward, (B) forward + backward -- sharing
+        one memory pool.  ~95 launches of (A) and ~30 of (B) become two graph launches: no
+        per-launch host cost, no allocator traffic, no host synchronisation (fixed-capacity tile
+        lists; an overflow is read back after the replay).  The gradient all-reduce is launched
+        between the two replays, so it runs under (B) exactly as in the eager schedule.  No collective
+        is issued in here: a failure leaves every rank with the same collective history."""
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         mode = "thread_local" if P.active(world) else "global"   # other threads (RCCL watchdog) may
         with torch.cuda.graph(ga, capture_error_mode=mode):  # call into the runtime meanwhile
@@ -532,18 +538,26 @@ def main():
     if args.launch in ("graph", "auto"):
         from pixelsplat_amd.raster import captured_overflow_flags
         list_cap[0] = (int(D_total * 1.25) + 4095) // 4096 * 4096
+        local_ok = True
         try:
-            capture_graphs()
-            launch_mode = "hipgraph"
-        except Exception as err:       # capture not possible in this build: the eager schedule
-            print(f"[bench] hipGraph capture failed ({type(err).__name__}: {err}); "
-                  f"falling back to eager launches", file=sys.stderr)
-            launch_fallback = f"{type(err).__name__}: {err}"[:300]
-            torch.cuda.synchronize()
-        if world > 1:   # one mode for the whole job: any rank's failed capture sends every rank to eager
-            all_ok = -P.max_over_ranks(-1.0 if launch_mode == "hipgraph" else 0.0, world, dev) > 0.5
-            if launch_mode == "hipgraph" and not all_ok:
-                launch_mode, launch_fallback = "eager", "another rank's capture failed"
+            capture_warm_up()
+        except Exception as err:
+            if world > 1:      # peers are inside the warm-up's collectives: no consistent way back
+                raise
+            local_ok, launch_fallback = False, f"warm-up: {type(err).__name__}: {err}"[:300]
+        if local_ok:
+            try:
+                capture_graphs()
+            except Exception as err:   # capture not possible in this build: the eager schedule
+                print(f"[bench] hipGraph capture failed ({type(err).__name__}: {err}); "
+                      f"falling back to eager launches", file=sys.stderr)
+                local_ok, launch_fallback = False, f"{type(err).__name__}: {err}"[:300]
+                torch.cuda.synchronize()
+        # one mode for the whole job: any rank's failed capture sends every rank to eager (every rank
+        # reaches this point with the same collective history: warm-up done, none in the capture)
+        launch_mode, why = P.choose_launch_mode(args.launch, local_ok, world, dev)
+        if why is not None and launch_fallback is None:
+            launch_fallback = why
         if launch_mode == "hipgraph":
             try:
                 step()

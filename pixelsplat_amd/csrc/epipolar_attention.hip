@@ -21,14 +21,6 @@
 #ifndef PS_ABLATE_ATTN
 #define PS_ABLATE_ATTN 0
 #endif
-// PS_ABLATE_DFMAP (same kind of experiment on the two-pass feature-map gradient's gather kernel):
-// 1: the walk without its LDS read-modify-writes, 2: without the token-row loads
-#ifndef PS_DFMAP_BINNED
-#define PS_DFMAP_BINNED 1     // 0: the round-2 gather (every tile sweeps the casting view's rays)
-#endif
-#ifndef PS_ABLATE_DFMAP
-#define PS_ABLATE_DFMAP 0
-#endif
 
 namespace ps {
 
@@ -1102,9 +1094,8 @@ epipolar_dfmap_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
 //     -- the gradient w.r.t. the gathered feature of that token -- and streams it out
 //     (b v ov r s c floats: what the reference's autograd holds as d(kv); 0.94 GB at the paper
 //     config, written and read once);
-//   pass 2 (dfmap_gather_kernel): the same tile-owner scatter as above, but a (ray, tile) item
-//     only loads the sample positions, and per token ONE 512-byte row of g_t: 34 instructions
-//     per (token, tile) visit, ~1.6 GB of reads.
+//   pass 2 (dfmap_list_gather_kernel, further down): the same tile-owner scatter as above, but over
+//     per-tile token lists built by a binning pass; per token ONE 512-byte row of g_t is loaded.
 // Same fixed summation order per pixel (view, ray, sample, corner) => bit-reproducible; the
 // value differs from the single pass only by the association of the layer / head sum.
 // ------------------------------------------------------------------------------------
@@ -1173,207 +1164,6 @@ epipolar_token_grad_kernel(AttnDims dm, const uint8_t* __restrict__ flags, Fgrad
   }
 }
 
-#ifndef PS_DF_TOKGROUP
-#define PS_DF_TOKGROUP 4
-#endif
-constexpr int kDfTokGroup = PS_DF_TOKGROUP;   // token rows in flight per wave in pass 2
-
-template <int CPL, int TS>
-__global__ void __launch_bounds__(kDfWaves* kWave)
-epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ xy,
-                             const uint32_t* __restrict__ boxes, const float* __restrict__ tg,
-                             const uint32_t* __restrict__ order, float* __restrict__ dfmap) {
-  extern __shared__ __attribute__((aligned(16))) float tiles[];  // [kDfWaves][TS*TS pixels + dummy][c]
-  using V = typename LaneVec<CPL>::type;
-  const int R = dm.h * dm.w, ovn = dm.v - 1;
-  const int tiles_x = (dm.w + TS - 1) / TS, tiles_y = (dm.h + TS - 1) / TS;
-  // Blocks run longest-first: the samples of converging epipolar lines pile up on one side of the
-  // image (20 to 2600 token visits per tile at the paper config) and the blocks are dispatched in
-  // index order, so the heavy tiles must not come last.  (No XCD affinity needed any more: a
-  // token's row is read by the 1-4 tiles it touches, not by every tile of its line.)
-  if ((int)blockIdx.x >= n_work) return;
-  const int work = (int)order[blockIdx.x];
-  const int tile_id = work % (tiles_x * tiles_y);
-  const int src_bv = work / (tiles_x * tiles_y);                // (b, source view)
-  const int b = src_bv / dm.v, sv = src_bv % dm.v;
-  const int tx0 = (tile_id % tiles_x) * TS, ty0 = (tile_id / tiles_x) * TS;
-  const int tx1 = min(tx0 + TS, dm.w) - 1, ty1 = min(ty0 + TS, dm.h) - 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c0 = lane * CPL;
-  const bool lane_c = c0 < dm.c;
-  const int cl = lane_c ? c0 : 0;
-  const int tile_floats = TS * TS * dm.c + max(dm.c, kWave * CPL);   // + dummy slots
-  float* tile = tiles + (size_t)wv * tile_floats;
-  float* lane_base = tile + (lane_c ? 0 : TS * TS * dm.c) + c0;
-  const int lane_mul = lane_c ? 1 : 0;
-  for (int i = lane; i < tile_floats; i += kWave) tile[i] = 0.f;
-  wave_lds_sync();
-  uint16_t* list = reinterpret_cast<uint16_t*>(tiles + (size_t)kDfWaves * tile_floats) +
-                   (size_t)wv * (kDfChunk / kDfWaves);
-  const int ngroups = (dm.s + kWave - 1) / kWave;                // 1 when s <= 64
-
-  for (int v = 0; v < dm.v; ++v) {
-    if (v == sv) continue;
-    const int ov = sv < v ? sv : sv - 1;
-    const size_t bv = (size_t)b * dm.v + v;
-    const size_t ro0 = (bv * ovn + ov) * R;
-    for (int chunk0 = 0; chunk0 < R; chunk0 += kDfChunk) {
-      // 1. cull, lanes <-> rays, in two sweeps so that the loads do not wait for each other:
-      //    (a) the packed boxes of the wave's rays against the tile, four 64-ray groups per trip
-      //        (four independent loads in flight), candidates appended to the wave's list;
-      //    (b) the exact segment-vs-tile test on the candidates, 64 at a time: ONE round of
-      //        sample-position loads per 64 candidates instead of one per 64 rays.
-      //    (The single-pass kernel tests group by group: 16 x 2 dependent latencies per view.)
-      int count = 0;
-      const int r_end = min(chunk0 + kDfChunk, R);
-      for (int r0 = chunk0 + wv * kWave; r0 < r_end; r0 += 4 * kDfWaves * kWave) {
-        uint32_t bx[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = r0 + u * kDfWaves * kWave + lane;
-          bx[u] = r < r_end ? boxes[ro0 + r] : 0x00FF00FFu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = r0 + u * kDfWaves * kWave + lane;
-          const uint32_t box = bx[u];
-          const int bx0 = box & 255, bx1 = (box >> 8) & 255, by0 = (box >> 16) & 255, by1 = box >> 24;
-          const bool hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
-          const uint64_t m = __ballot(hit);
-          if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)(r - chunk0);
-          count += __popcll(m);
-        }
-      }
-      wave_lds_sync();
-      const int n_cand = count;
-      count = 0;
-      for (int c0 = 0; c0 < n_cand; c0 += kWave) {
-        const bool on = c0 + lane < n_cand;
-        const int rl = on ? (int)list[c0 + lane] : 0;
-        bool hit = false;
-        if (on) {
-          // exact test: a sample touches the tile iff its pixel position lies in
-          // [tx0 - 1, tx1 + 1) x [ty0 - 1, ty1 + 1); the samples lie on the segment between
-          // the first and the last one (Liang-Barsky clip, 0.02 px of slack for rounding)
-          const size_t so = (ro0 + chunk0 + rl) * dm.s;
-          const float2 p0 = *reinterpret_cast<const float2*>(xy + 2 * so);
-          const float2 p1 = *reinterpret_cast<const float2*>(xy + 2 * (so + dm.s - 1));
-          const Corner ca = corner_of(p0.x, p0.y, dm.w, dm.h), cb = corner_of(p1.x, p1.y, dm.w, dm.h);
-          const float ax = (float)ca.x0 + ca.wx, ay = (float)ca.y0 + ca.wy;
-          const float dx = (float)cb.x0 + cb.wx - ax, dy = (float)cb.y0 + cb.wy - ay;
-          const float xlo = (float)tx0 - 1.02f, xhi = (float)tx1 + 1.02f;
-          const float ylo = (float)ty0 - 1.02f, yhi = (float)ty1 + 1.02f;
-          float ta = 0.f, tb = 1.f;
-          auto clip = [&](float pp, float qq) {       // pp * t <= qq
-            if (pp == 0.f) { if (qq < 0.f) tb = -1.f; return; }
-            const float rr = qq / pp;
-            if (pp < 0.f) ta = fmaxf(ta, rr); else tb = fminf(tb, rr);
-          };
-          clip(-dx, ax - xlo); clip(dx, xhi - ax); clip(-dy, ay - ylo); clip(dy, yhi - ay);
-          hit = ta <= tb;
-        }
-        const uint64_t m = __ballot(hit);
-        wave_lds_sync();               // every lane has read its candidate: compact in place
-        if (hit) list[count + __popcll(m & lanemask_lt())] = (uint16_t)rl;
-        count += __popcll(m);
-        wave_lds_sync();
-      }
-      wave_lds_sync();
-      if (count == 0) continue;
-      // 2. walk the list: sample positions one item ahead, token rows kDfTokGroup at a time (all
-      //    loads of a group issued before the first read-modify-write).  A deeper pipeline --
-      //    the next item's rows in flight during this item's LDS updates -- measured SLOWER
-      //    (0.69 -> 0.74 ms): the kernel is bound by issue + LDS, not by the row latency.
-      const int n_items = count * ngroups;
-      auto fetch_xy = [&](int item) {
-        const int rr = chunk0 + list[item / ngroups];
-        const int si = min((item % ngroups) * kWave + lane, dm.s - 1);
-        return *reinterpret_cast<const float2*>(xy + 2 * ((ro0 + rr) * dm.s + si));
-      };
-      float2 cur = fetch_xy(0);
-      for (int item = 0; item < n_items; ++item) {
-        const float2 nxt = fetch_xy(min(item + 1, n_items - 1));
-        const int rr = chunk0 + list[item / ngroups];
-        const int sbase = (item % ngroups) * kWave;
-        const bool tok = sbase + lane < dm.s;
-        const Corner kq = corner_of(cur.x, cur.y, dm.w, dm.h);
-        int off[4]; float wt[4]; bool any = false;
-#pragma unroll
-        for (int cr = 0; cr < 4; ++cr) {
-          const int xx = kq.x0 + (cr & 1), yy = kq.y0 + (cr >> 1);
-          const bool in = tok && xx >= tx0 && xx <= tx1 && yy >= ty0 && yy <= ty1;
-          const float wx = (cr & 1) ? kq.wx : 1.f - kq.wx, wy = (cr >> 1) ? kq.wy : 1.f - kq.wy;
-          off[cr] = (in ? (yy - ty0) * TS + (xx - tx0) : TS * TS) * dm.c;
-          wt[cr] = in ? wx * wy : 0.f;
-          any |= in;
-        }
-        uint64_t toks = __ballot(any);
-        const float* rows = tg + ((ro0 + rr) * dm.s + sbase) * (size_t)dm.c + cl;
-        while (toks) {
-          int tl[kDfTokGroup];
-          int n = 0;
-#pragma unroll
-          for (int q = 0; q < kDfTokGroup; ++q) {
-            tl[q] = toks ? __builtin_ctzll(toks) : 0;
-            if (toks) { toks &= toks - 1; ++n; }
-          }
-          float df[kDfTokGroup][CPL];
-#if PS_ABLATE_DFMAP == 2      // timing experiment: the walk without the token-row loads
-#pragma unroll
-          for (int q = 0; q < kDfTokGroup; ++q)
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) df[q][i] = cur.x;
-#else
-#pragma unroll
-          for (int q = 0; q < kDfTokGroup; ++q)
-            if (q < n) load_cpl<CPL>(rows + (size_t)tl[q] * dm.c, df[q]);
-#endif
-#if PS_ABLATE_DFMAP == 1      // timing experiment: rows loaded, no LDS read-modify-writes
-#pragma unroll
-          for (int q = 0; q < kDfTokGroup; ++q)
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) asm volatile("" :: "v"(df[q][i]));
-#else
-#pragma unroll
-          for (int q = 0; q < kDfTokGroup; ++q) {
-            if (q < n) {
-              V* dst[4]; V val[4];
-#pragma unroll
-              for (int cr = 0; cr < 4; ++cr) {
-                dst[cr] = reinterpret_cast<V*>(lane_base + lane_bcast_i(off[cr], tl[q]) * lane_mul);
-                val[cr] = *dst[cr];
-              }
-#pragma unroll
-              for (int cr = 0; cr < 4; ++cr) {
-                const float wgt = lane_bcast(wt[cr], tl[q]);
-                float* f = reinterpret_cast<float*>(&val[cr]);
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) f[i] = fmaf(wgt, df[q][i], f[i]);
-                *dst[cr] = val[cr];
-              }
-            }
-          }
-#endif
-        }
-        cur = nxt;
-      }
-      wave_lds_sync();
-    }
-  }
-  __syncthreads();
-  float* out = dfmap + (size_t)src_bv * R * dm.c;
-  const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-  for (int i = threadIdx.x; i < tw * th * dm.c; i += kDfWaves * kWave) {
-    const int pix = i / dm.c, ch = i - pix * dm.c;
-    const int py = pix / tw, px = pix - py * tw;
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < kDfWaves; ++k)
-      acc += tiles[(size_t)k * tile_floats + (py * TS + px) * dm.c + ch];
-    out[((size_t)(ty0 + py) * dm.w + tx0 + px) * dm.c + ch] = acc;
-  }
-}
-
 // ------------------------------------------------------------------------------------
 // Binned gather (round 3): the per-tile token lists are BUILT once per flush by a stable count /
 // scan / fill pass over the tokens -- the rasterizer's binning scheme -- instead of being
@@ -1395,6 +1185,9 @@ epipolar_dfmap_gather_kernel(AttnDims dm, int n_work, const float* __restrict__ 
 // single-scene launches bit for bit (tests/test_epipolar_gpu.py).
 // ------------------------------------------------------------------------------------
 constexpr int kBinTokens = 256;          // tokens per count / fill block
+constexpr int kBinTileBits = 12;         // the fill's wave match compares this many bits of a tile index
+constexpr size_t kBinFillLdsMax = 64 * 1024;   // dynamic LDS the fill kernel may ask for
+constexpr int kDfTokGroup = 4;           // token rows in flight per wave in the list gather
 
 struct BinDims {
   int tiles_x, tiles_y, tiles;           // TS x TS tiles per map
@@ -1588,7 +1381,8 @@ epipolar_bin_fill_kernel(AttnDims dm, const float* __restrict__ xy, const uint8_
   }
   __syncthreads();
   // footprint slot by slot: rank among the wave's lanes with the same tile (match by ballots over
-  // the 12 bits of a tile index: maps <= 255 x 255, tiles <= 64 x 64), the leader advances the start
+  // the kBinTileBits bits of a tile index; the launcher refuses maps with more tiles), the leader
+  // advances the start
   const uint64_t lt = lanemask_lt();
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1596,7 +1390,7 @@ epipolar_bin_fill_kernel(AttnDims dm, const float* __restrict__ xy, const uint8_
     const uint32_t tl = on ? (uint32_t)k.tile[j] : 0u;
     uint64_t mask = __ballot(on);
 #pragma unroll
-    for (int bit = 0; bit < 12; ++bit) {
+    for (int bit = 0; bit < kBinTileBits; ++bit) {
       const bool b1 = (tl >> bit) & 1u;
       const uint64_t bal = __ballot(b1);
       mask &= b1 ? bal : ~bal;
@@ -1829,10 +1623,15 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
   const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
   if (token_grad != nullptr) {     // two passes: token gradients once, then the tile gather
     dim3 g1((unsigned)((n_ro + 3) / 4)), b1(256);
-#if PS_DFMAP_BINNED
     // binned gather: the per-tile token lists first (count / scan / offsets + order / fill), from the
     // geometry alone; `boxes` is the scratch: cnt | tile_len | tile_off | order | list
     const BinDims bd = make_bin_dims<TS>(dm);
+    // the fill ranks lanes by kBinTileBits bits of the tile index and keeps one start per (wave, tile)
+    // in LDS: both bound the tile count (today implied by w, h <= 255 with TS = 4; checked here so that
+    // raising either limit cannot silently give colliding ranks)
+    if (bd.tiles > (1 << kBinTileBits) ||
+        (size_t)(kBinTokens / kWave) * bd.tiles * sizeof(uint32_t) > kBinFillLdsMax)
+      return PS_ERR_UNSUPPORTED;
     uint32_t* cnt = boxes;
     uint32_t* tile_len = cnt + (size_t)bd.n_src * bd.blocks_per_src * bd.tiles;
     uint32_t* tile_off = tile_len + n_work;
@@ -1861,28 +1660,6 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
     if (dm.c <= 64) PS_TG(1); else if (dm.c <= 128) PS_TG(2); else PS_TG(4);
 #undef PS_TG
     return PS_OK;
-#else
-    uint32_t* tile_work = boxes + n_ro;
-    uint32_t* order = boxes + n_ro + n_work;
-    if (hipMemsetAsync(tile_work, 0, (size_t)n_work * sizeof(uint32_t), st) != hipSuccess)
-      return PS_ERR_LAUNCH;
-    hipLaunchKernelGGL(epipolar_ray_box_kernel<TS>, dim3((unsigned)((n_ro + 255) / 256)), dim3(256),
-                       (size_t)tiles * sizeof(uint32_t), st, dm, xy, flags, boxes, tile_work);
-    hipLaunchKernelGGL(epipolar_tile_order_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_work,
-                       order);
-#define PS_TG(CPL)                                                                              \
-  do {                                                                                          \
-    if (n_layers == 1) hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 1>), g1, b1, 0, st,  \
-                                          dm, flags, L, token_grad);                            \
-    else hipLaunchKernelGGL((epipolar_token_grad_kernel<CPL, 2>), g1, b1, 0, st, dm, flags, L,  \
-                            token_grad);                                                        \
-    hipLaunchKernelGGL((epipolar_dfmap_gather_kernel<CPL, TS>), g2, b2, sm2, st, dm, n_work,    \
-                       xy, boxes, token_grad, order, dfmap);                                    \
-  } while (0)
-    if (dm.c <= 64) PS_TG(1); else if (dm.c <= 128) PS_TG(2); else PS_TG(4);
-#undef PS_TG
-    return PS_OK;
-#endif
   }
   // single pass: the packed ray boxes only
   hipLaunchKernelGGL(epipolar_ray_box_kernel<TS>, dim3((unsigned)((n_ro + 255) / 256)), dim3(256), 0, st,

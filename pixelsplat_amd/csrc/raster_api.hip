@@ -36,7 +36,8 @@ std::vector<Pending> g_pending;
 struct Roctx {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
-  bool env_on = false;
+  // the marker library is only looked up when ranges are asked for (PS_ROCTX=1, ps_profile_enable(2),
+  // or an explicit ps_roctx_available()): a host process that never profiles loads nothing
   Roctx() {
     for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1",
                              "libroctx64.so", "libroctx64.so.4"}) {
@@ -45,13 +46,16 @@ struct Roctx {
         pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
         if (push && pop) break;
         push = nullptr; pop = nullptr;
+        dlclose(h);                    // not a marker library after all
       }
     }
-    const char* e = getenv("PS_ROCTX");
-    env_on = e && e[0] && e[0] != '0';
   }
 };
 Roctx& roctx() { static Roctx r; return r; }
+bool roctx_env_on() {
+  static const bool on = [] { const char* e = getenv("PS_ROCTX"); return e && e[0] && e[0] != '0'; }();
+  return on;
+}
 const char* kRangeNames[] = {"ps:preprocess_forward", "ps:depth_sort", "ps:tile_bins", "ps:tiles_forward",
                              "ps:tiles_backward", "ps:preprocess_backward", "ps:memset",
                              "ps:epipolar_geometry", "ps:epipolar_attention_forward",
@@ -64,8 +68,10 @@ static_assert(sizeof(kRangeNames) / sizeof(kRangeNames[0]) == G_COUNT, "one rang
 struct Scope {
   hipEvent_t a = nullptr, b = nullptr; int group; hipStream_t st; bool on; bool range = false;
   Scope(int g, hipStream_t s) : group(g), st(s), on((g_profile_on.load() & 1) != 0) {
-    Roctx& rx = roctx();
-    if (rx.push && (rx.env_on || (g_profile_on.load() & 2))) { rx.push(kRangeNames[g]); range = true; }
+    if (roctx_env_on() || (g_profile_on.load() & 2)) {     // (no library lookup otherwise)
+      Roctx& rx = roctx();
+      if (rx.push) { rx.push(kRangeNames[g]); range = true; }
+    }
     if (!on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
     hipEventRecord(a, st);

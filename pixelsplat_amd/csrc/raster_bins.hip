@@ -13,10 +13,6 @@
 // cheap integer VALU instead of the reference's 5-6 radix passes over D 12-byte pairs.
 #include "raster_common.h"
 
-#ifndef PS_BIN_UNROLL
-#define PS_BIN_UNROLL 1   // > 1: timing experiment below (tools/build_variant.sh x -DPS_BIN_UNROLL=4)
-#endif
-
 namespace ps {
 
 template <bool WRITE>
@@ -64,38 +60,6 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
         in_band = (r.x >> 16) <= band_hi && (r.y >> 16) > band_lo;
       }
       uint64_t hits = __ballot(in_band);
-#if PS_BIN_UNROLL > 1
-      // experiment (not the default build): the survivors PS_BIN_UNROLL at a time, their LDS reads
-      // issued together -- the walk below pays one LDS round trip (rect -> test -> id) per survivor
-      while (hits) {
-        uint32_t ix[PS_BIN_UNROLL];
-        bool valid[PS_BIN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < PS_BIN_UNROLL; ++u) {
-          valid[u] = hits != 0;
-          ix[u] = valid[u] ? i0 + (uint32_t)__builtin_ctzll(hits) : i0;
-          hits &= hits - 1;        // (0 & anything = 0 once exhausted)
-        }
-        uint2 rr[PS_BIN_UNROLL];
-        uint32_t id[PS_BIN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < PS_BIN_UNROLL; ++u) {
-          rr[u] = s_rect[ix[u]];
-          id[u] = WRITE ? s_idx[ix[u]] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < PS_BIN_UNROLL; ++u) {       // ascending: the lists stay depth-sorted
-          if (valid[u] && tile_ok && rect_covers_packed(rr[u], Tt, T1)) {
-            if (!WRITE) {
-              ++k;
-            } else {
-              if (off < capacity) point_list[off] = id[u];
-              ++off;
-            }
-          }
-        }
-      }
-#else
       while (hits) {
         const uint32_t i = i0 + (uint32_t)__builtin_ctzll(hits);
         hits &= hits - 1;
@@ -109,7 +73,6 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
           }
         }
       }
-#endif
     }
     if (!WRITE && tile_ok) *c = k;
   }

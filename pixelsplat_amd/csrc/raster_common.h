@@ -13,10 +13,7 @@ constexpr int kTile = 16;               // 16x16 pixel tiles (bin parity with th
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 constexpr int kRecFloats = 12;          // one 48-byte record per (view, gaussian)
 constexpr int kGradFloats = 9;          // dxy(2) dconic(3) dopacity(1) drgb(3)
-#ifndef PS_SLOT_FLOATS
-#define PS_SLOT_FLOATS 12
-#endif
-constexpr int kSlotFloats = PS_SLOT_FLOATS;  // per-(tile, entry) gradient slot: 9 used, 16-byte aligned
+constexpr int kSlotFloats = 12;         // per-(tile, entry) gradient slot: 9 used, 16-byte aligned
 constexpr int kInvSlots = 4;            // Gaussians touching <= 4 tiles use slots, larger ones atomics
 // records[7] of a Gaussian touching <= kInvSlots tiles: bit 31 | (rect width - 1) << 29 |
 // ymin << 15 | xmin (tile units); 0 for larger rects (and for tile grids over 16383 rows)
@@ -26,10 +23,7 @@ constexpr uint32_t kSmallFlag = 0x80000000u;
 constexpr int kSortThreads = 1024;      // 16 waves x 4 items: the per-wave ranking chain is the
 constexpr int kSortItems = 4;           // latency of the scatter kernel (16 items: 62 us per pass)
 constexpr int kSortChunk = kSortThreads * kSortItems;  // 4096 keys per block
-#ifndef PS_BIN_CHUNK
-#define PS_BIN_CHUNK 1024
-#endif
-constexpr int kBinChunk = PS_BIN_CHUNK;                 // sorted entries per binning block
+constexpr int kBinChunk = 1024;                         // sorted entries per binning block
 
 struct Dims {
   int S, vps, V, G, H, W, gx, gy, tiles;

@@ -16,6 +16,8 @@ N ranks, barrier, max-over-ranks timing, per-rank seeds (the reference seeds per
 """
 from __future__ import annotations
 
+import collections
+
 import os
 
 import torch
@@ -101,6 +103,26 @@ def max_over_ranks(value: float, world: int, device: torch.device | str = "cpu")
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def agree_all(ok: bool, world: int, device: torch.device | str = "cpu") -> bool:
+    """True iff `ok` on EVERY rank (one MIN all-reduce).  Call it only at points where all ranks have
+    issued the same collectives so far -- bench.py asks after the capture warm-up and after the capture,
+    phases that contain no partial collective history (a rank that fails INSIDE a phase with collectives
+    in flight must abort the job instead: its peers are waiting in a collective it will never join)."""
+    return max_over_ranks(0.0 if ok else 1.0, world, device) < 0.5
+
+
+def choose_launch_mode(requested: str, local_capture_ok: bool, world: int,
+                       device: torch.device | str = "cpu") -> tuple[str, str | None]:
+    """One launch mode for the whole job: ("hipgraph", None) only if every rank captured, else
+    ("eager", reason).  `requested` = "eager" short-circuits without a collective."""
+    if requested == "eager":
+        return "eager", None
+    if agree_all(local_capture_ok, world, device):
+        return "hipgraph", None
+    return "eager", ("this rank's capture failed" if not local_capture_ok
+                     else "another rank's capture failed")
 
 
 def gather_over_ranks(value: float, world: int, device: torch.device | str = "cpu") -> list[float]:
@@ -217,7 +239,9 @@ class GradientReducer:
         self._hooks = []
         self._next = 0                    # next bucket to launch (index order)
         self._given: set[int] = set()     # parameters whose .grad the reducer supplied (unused on this rank)
-        self._exposed = []                # (start, end) event pairs / seconds around finish()'s wait
+        # (start, end) event pairs / seconds around finish()'s wait: the last 256 steps only (a long
+        # training run must not keep two live HIP events per step for ever)
+        self._exposed = collections.deque(maxlen=256)
         self._rebucket = rebucket_after_first_step
         self.extra = None
         self.extra_chunk = max(1, bucket_bytes // 4)
@@ -450,7 +474,7 @@ class GradientReducer:
         if torch.cuda.is_available() and any(not isinstance(e, float) for e in self._exposed):
             torch.cuda.synchronize()
         vals = [e * 1e3 if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in self._exposed]
-        return vals if last is None else vals[-last:]
+        return vals if last is None else vals[-last:] if last > 0 else []
 
     def remove(self) -> None:
         for h in self._hooks:

@@ -302,3 +302,66 @@ def test_forced_one_rank_communicator_runs_the_whole_reducer():
     assert steps == 3 and rebucketed and nranks == 1
     assert l_hooks > 0 and l_all > l_hooks and n_exposed == 3
     assert mx == 2.5 and gathered == [1.5]
+
+
+# ---- one launch mode for the whole job (bench.py --launch auto, VERDICT r3 #7 / ADVICE r3) --------
+def _launch_mode_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from pixelsplat_amd import parallel as P
+
+    _, w, _ = P.init_from_env("gloo")
+    # stand-in for bench.py's sequence: warm-up (collectives), capture (none), agreement, timed steps
+    P.barrier(w)
+    rounds = []
+    for failing_rank in (None, 1, 0):
+        capture_ok = rank != failing_rank                      # the mocked hipGraph capture
+        rounds.append(P.choose_launch_mode("auto", capture_ok, w))
+    rounds.append(P.choose_launch_mode("eager", True, w))      # no collective issued for "eager"
+    # the slowest rank sets the job's time whatever the launch mode: rank r takes (1 + r) s for 10 steps
+    elapsed = P.max_over_ranks(1.0 + rank, w)
+    out[rank] = (rounds, elapsed, P.aggregate_throughput(28, 10, w, elapsed),
+                 P.gather_over_ranks(float(rank), w))
+    P.barrier(w)
+    P.shutdown(w)
+
+
+def test_failed_capture_on_one_rank_sends_every_rank_to_eager():
+    world, port = 3, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_launch_mode_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        rounds, elapsed, value, ranks = res[rank]
+        assert rounds[0] == ("hipgraph", None)                 # every capture worked
+        for failing, r in ((1, rounds[1]), (0, rounds[2])):    # one rank's capture failed: ALL eager
+            assert r[0] == "eager"
+            assert r[1] == ("this rank's capture failed" if rank == failing
+                            else "another rank's capture failed")
+        assert rounds[3] == ("eager", None)
+        assert elapsed == 3.0                                  # the slowest rank's time ...
+        assert value == 3 * 28 * 10 / 3.0                      # ... prices the whole job's views
+        assert ranks == [0.0, 1.0, 2.0]
+
+
+def test_exposed_wait_history_is_bounded():
+    """finish() must not keep one timing record per step for ever."""
+    from pixelsplat_amd import parallel as P
+
+    os.environ["PIXELSPLAT_FORCE_COMM"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ["MASTER_PORT"] = str(_free_port())
+    try:
+        P.init_from_env("gloo")
+        p = torch.nn.Parameter(torch.ones(5))
+        red = P.GradientReducer([p], 1)
+        for _ in range(300):
+            p.grad = None
+            (p * 2).sum().backward()
+            red.finish()
+        assert len(red.exposed_ms()) == 256 and len(red.exposed_ms(last=20)) == 20
+        P.shutdown(1)
+    finally:
+        os.environ.pop("PIXELSPLAT_FORCE_COMM", None)
