@@ -46,6 +46,10 @@ def parse():
     p.add_argument("--views", type=int, default=4, help="target views per scene")
     p.add_argument("--context-views", type=int, default=2,
                    help="context views per scene (3: BASELINE configs[3], acid 3-view)")
+    p.add_argument("--scene", choices=["survey", "dense", "opaque", "large"], default="survey",
+                   help="Gaussian distribution (pixelsplat_amd/synthetic.py SCENES): survey = SURVEY 8d's recipe "
+                        "(the BASELINE workload); dense = >= 80 %% of the pairs in frame, D/G >= 2; opaque = opacity "
+                        "U(0.5, 1), early termination; large = scales x 3, the > 4-tile atomic path")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-probes", action="store_true",
                    help="skip the SURVEY 8(f) side probes (adapter / depth / head chain) after the timed "
@@ -325,7 +329,8 @@ def main():
     hw = (args.size, args.size)
     b, v = args.batch, args.views
     vc = args.context_views
-    ctx, tgt, g, target = make_workload(b, hw, v_ctx=vc, v_tgt=v, seed=P.rank_seed(0, rank))
+    ctx, tgt, g, target = make_workload(b, hw, v_ctx=vc, v_tgt=v, seed=P.rank_seed(0, rank),
+                                        scene=args.scene)
     G = g.means.shape[1]
     V = b * v
 
@@ -372,8 +377,9 @@ def main():
         view_emb = et.view_embeddings(view_shuffle) if vc > 2 else None  # epipolar_transformer.py:126-131
         folds = et.fold_layers(view_emb)
         grad_batch = FeatureGradBatch()
+        feat_kv = grad_batch.attach(feat)     # as EpipolarTransformer.forward: deferred map gradient
         for (attn, _ff), folded in zip(et.transformer.layers, folds):
-            x = et.fused_block(attn, x, feat, geo, view_emb=view_emb, folded=folded, batch=grad_batch)
+            x = et.fused_block(attn, x, feat_kv, geo, view_emb=view_emb, folded=folded, batch=grad_batch)
         return x.square().mean()
 
     list_cap = [0]     # > 0: fixed-capacity tile lists (no host sync in the forward)
@@ -516,6 +522,21 @@ def main():
     counts, _, _ = export_bins(aux["cfg"], aux["state"], aux["layout"], aux["point_list"])
     D_total = int(counts.to(torch.int64).sum().item())
     n_visible = int((aux["radii"] > 0).sum().item())
+    # pairs whose rect covers more than 4 tiles: the tile backward accumulates their gradient with
+    # float atomics instead of private slots (rects: [xmin, ymin, xmax, ymax) in tiles)
+    from pixelsplat_amd.raster import state_views as _sv
+    _r = _sv(aux["cfg"], aux["state"], aux["layout"])["rects"].to(torch.int32)
+    _tiles = (_r[..., 2] - _r[..., 0]) * (_r[..., 3] - _r[..., 1])
+    n_large = int(((aux["radii"].reshape(_tiles.shape) > 0) & (_tiles > 4)).sum().item())
+    final_T_stats = _sv(aux["cfg"], aux["state"], aux["layout"])
+    _nc = final_T_stats["n_contrib"].to(torch.float32).reshape(V, hw[0] // 16, 16, hw[1] // 16, 16) \
+        if hw[0] % 16 == 0 and hw[1] % 16 == 0 else None
+    if _nc is not None:     # where a pixel's walk ends inside its tile's list (1.0 = never stops early)
+        _len = counts.to(torch.float32).reshape(V, hw[0] // 16, 1, hw[1] // 16, 1).clamp(min=1)
+        walk_end_median = round(float((_nc / _len).median().item()), 3)
+    else:
+        walk_end_median = None
+    del _r, _tiles, final_T_stats, _nc
     vps_np = aux["view_params"].cpu().numpy()
     gpu_images = img.detach().cpu().numpy()
     gpu_fwd = None
@@ -687,6 +708,8 @@ def main():
         global PMC_TAG
         PMC_TAG = {(256, 256, 7, 4, 2): "c2", (256, 256, 4, 4, 3): "c4",
                    (512, 512, 2, 4, 2): "c5"}.get((hw[0], hw[1], b, v, vc))
+        if args.scene != "survey":      # counters are taken on the BASELINE (survey) workload only
+            PMC_TAG = None
         is_c2 = PMC_TAG is not None
         traffic, traffic_src = pmc_traffic(dom)
         valu_ms = pmc_valu_busy_ms(dom) if is_c2 else None
@@ -697,14 +720,19 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{'acid' if vc > 2 else 're10k'} {vc}-view, {hw[0]}x{hw[1]}, batch_size={b} per GPU, {v} target "
-                            f"views/scene{BASELINE_TAG.get((hw[0], b, v, vc), '')}: epipolar sampler + 2 "
+                            f"views/scene{BASELINE_TAG.get((hw[0], b, v, vc), '') if args.scene == 'survey' else f' [scene distribution: {args.scene} -- NOT a BASELINE config]'}: epipolar sampler + 2 "
                             f"cross-attention layers on [{b},{vc},{d_feat},{hA},{wA}] (A) + "
                             f"rasterizer (B), fwd+bwd",
+                "scene": args.scene,
                 "epipolar_rays": b * vc * hA * wA, "epipolar_samples_per_ray": n_samp,
                 "epipolar_kv_tokens_per_ray": n_samp * (vc - 1),
                 "gaussians_per_scene": G, "views_per_step_per_gpu": V,
                 "tile_list_entries_D": D_total, "visible_gaussian_views": n_visible,
-                "D_over_GV": round(D_total / (G * V), 3), "parallelism": f"dp{world}",
+                "D_over_GV": round(D_total / (G * V), 3),
+                "visible_frac": round(n_visible / (G * V), 3),
+                "atomic_path_pairs_frac": round(n_large / max(n_visible, 1), 4),
+                "median_walk_end_over_list_length": walk_end_median,
+                "parallelism": f"dp{world}",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),

@@ -461,9 +461,8 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* desc, int32_t n_layers,
 size_t ps_epipolar_token_grad_floats(const PsEpipolarDesc* desc);
 /* uint32 words `ray_boxes` must hold for the two-pass call: the scratch of its binned gather -- per
  * (source map, block of 256 tokens, 4x4 tile) counts, per tile a length, an offset and a slot of the
- * longest-first block order, and the per-tile token lists (at most 4 entries per token) -- or, for
- * the round-2 gather, one packed pixel box per (ray, other view) + two words per tile (the
- * single-pass calls need only the first b*v*(v-1)*h*w words). */
+ * longest-first block order, and the per-tile token lists (at most 4 entries per token); the
+ * single-pass call needs only the first b*v*(v-1)*h*w words (one packed pixel box per ray and other view). */
 size_t ps_epipolar_ray_box_words(const PsEpipolarDesc* desc);
 int ps_epipolar_feature_grad_two_pass(const PsEpipolarDesc* desc, int32_t n_layers,
                                       const float* xy_sample, const uint8_t* flags,
@@ -471,6 +470,20 @@ int ps_epipolar_feature_grad_two_pass(const PsEpipolarDesc* desc, int32_t n_laye
                                       const float* const* dfbar, const float* const* ds,
                                       float* dfmap, uint32_t* ray_boxes, float* token_grad,
                                       void* stream);
+/* The same in two calls, for callers that overlap them with other work (the reference's autograd
+ * runs grid_sample's backward, epipolar_sampler.py:98-111, wherever the graph puts it; here the host
+ * decides): `_bins` builds the per-tile token lists of the binned gather into `ray_boxes`
+ * (ps_epipolar_ray_box_words words) from the sampling geometry ALONE -- it may run as soon as xy_sample /
+ * flags exist, e.g. on a side stream during the forward pass -- and `_binned` (token gradients + list
+ * gather) consumes them once the layers' gradients are there.  _two_pass == _bins then _binned. */
+int ps_epipolar_feature_bins(const PsEpipolarDesc* desc, const float* xy_sample, const uint8_t* flags,
+                             uint32_t* ray_boxes, void* stream);
+int ps_epipolar_feature_grad_binned(const PsEpipolarDesc* desc, int32_t n_layers,
+                                    const float* xy_sample, const uint8_t* flags,
+                                    const float* const* qt, const float* const* attn,
+                                    const float* const* dfbar, const float* const* ds,
+                                    float* dfmap, const uint32_t* ray_boxes, float* token_grad,
+                                    void* stream);
 
 /* w2c[i] = c2w[i]^-1 (4x4) and k_inv[i] = k[i]^-1 (3x3) for n cameras, one launch, no host
  * sync (replaces the sampler's torch.linalg.inv calls: src/geometry/epipolar_lines.py:167,

@@ -71,7 +71,7 @@ EXPORTS = [
     "ps_raster_forward_render", "ps_raster_forward_colors", "ps_raster_forward_bins", "ps_raster_forward_tiles", "ps_raster_backward", "ps_raster_backward_prepare",
     "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
     "ps_epipolar_attention_forward", "ps_epipolar_attention_backward", "ps_status_string", "ps_build_info", "ps_roctx_available",
-    "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_gemm_tn_colsum_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_epipolar_token_grad_floats", "ps_epipolar_ray_box_words", "ps_epipolar_feature_grad_two_pass", "ps_gaussian_adapter_views",
+    "ps_gemm_tn_workspace_bytes", "ps_gemm_tn_f32", "ps_gemm_tn_colsum_f32", "ps_invert_cameras", "ps_epipolar_feature_grad", "ps_epipolar_token_grad_floats", "ps_epipolar_ray_box_words", "ps_epipolar_feature_grad_two_pass", "ps_epipolar_feature_bins", "ps_epipolar_feature_grad_binned", "ps_gaussian_adapter_views",
     "ps_gaussian_adapter_forward", "ps_gaussian_adapter_backward",
     "ps_gaussian_head_forward", "ps_gaussian_head_backward",
     "ps_depth_sampler_forward", "ps_depth_sampler_backward",
@@ -160,6 +160,10 @@ def load():
     lib.ps_epipolar_ray_box_words.restype = C.c_size_t
     lib.ps_epipolar_feature_grad_two_pass.argtypes = [pe, C.c_int32] + [vp] * 10
     lib.ps_epipolar_feature_grad_two_pass.restype = C.c_int
+    lib.ps_epipolar_feature_bins.argtypes = [pe, vp, vp, vp, vp]
+    lib.ps_epipolar_feature_bins.restype = C.c_int
+    lib.ps_epipolar_feature_grad_binned.argtypes = [pe, C.c_int32] + [vp] * 10
+    lib.ps_epipolar_feature_grad_binned.restype = C.c_int
     lib.ps_gaussian_adapter_views.argtypes = [C.c_int32] * 4 + [vp] * 5
     lib.ps_gaussian_adapter_views.restype = C.c_int
     lib.ps_gaussian_adapter_forward.argtypes = [C.c_int32] * 4 + [C.c_float] * 3 + [vp] * 8

@@ -1603,15 +1603,19 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
                                  const uint8_t* flags, const float* const* qt,
                                  const float* const* attn, const float* const* dfbar,
                                  const float* const* ds, float* dfmap, uint32_t* boxes,
-                                 float* token_grad, hipStream_t st) {
+                                 float* token_grad, int phases, hipStream_t st) {
+  // phases (two-pass scheme only): bit 0 = build the per-tile token lists (geometry only: may run long
+  // before the gradients exist, on another stream), bit 1 = token gradients + list gather
   if (!attn_dims_ok(dm)) return PS_ERR_UNSUPPORTED;
-  if (n_layers < 1 || n_layers > kMaxFgradLayers) return PS_ERR_UNSUPPORTED;
   if (boxes == nullptr || dm.w > 255 || dm.h > 255) return PS_ERR_BAD_ARG;
-  FgradLayers L;
-  for (int l = 0; l < kMaxFgradLayers; ++l) {
-    const int s = l < n_layers ? l : 0;
-    L.attn[l] = attn[s]; L.ds[l] = ds[s]; L.dfbar[l] = dfbar[s]; L.qt[l] = qt[s];
-    if (!L.attn[l] || !L.ds[l] || !L.dfbar[l] || !L.qt[l]) return PS_ERR_BAD_ARG;
+  FgradLayers L{};
+  if (phases & 2) {
+    if (n_layers < 1 || n_layers > kMaxFgradLayers) return PS_ERR_UNSUPPORTED;
+    for (int l = 0; l < kMaxFgradLayers; ++l) {
+      const int s = l < n_layers ? l : 0;
+      L.attn[l] = attn[s]; L.ds[l] = ds[s]; L.dfbar[l] = dfbar[s]; L.qt[l] = qt[s];
+      if (!L.attn[l] || !L.ds[l] || !L.dfbar[l] || !L.qt[l]) return PS_ERR_BAD_ARG;
+    }
   }
   const size_t n_ro = (size_t)dm.b * dm.v * dm.h * dm.w * (dm.v - 1);
   constexpr int TS = 4;
@@ -1621,7 +1625,7 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
   const int cpl = dm.c <= 64 ? 1 : dm.c <= 128 ? 2 : 4;
   const size_t tile_floats = (size_t)TS * TS * dm.c + (dm.c > kWave * cpl ? dm.c : kWave * cpl);
   const size_t sm2 = (size_t)kDfWaves * tile_floats * sizeof(float) + kDfChunk * sizeof(uint16_t);
-  if (token_grad != nullptr) {     // two passes: token gradients once, then the tile gather
+  if (token_grad != nullptr || phases == 1) {     // two passes: token gradients once, then the tile gather
     dim3 g1((unsigned)((n_ro + 3) / 4)), b1(256);
     // binned gather: the per-tile token lists first (count / scan / offsets + order / fill), from the
     // geometry alone; `boxes` is the scratch: cnt | tile_len | tile_off | order | list
@@ -1638,15 +1642,18 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
     uint32_t* order = tile_off + n_work;
     uint32_t* list = order + n_work;
     const unsigned bin_blocks = (unsigned)(dm.b * dm.v * (dm.v - 1) * bd.blocks_per_pair);
-    hipLaunchKernelGGL(epipolar_bin_count_kernel<TS>, dim3(bin_blocks), dim3(kBinTokens),
-                       (size_t)bd.tiles * sizeof(uint32_t), st, dm, xy, flags, cnt);
-    hipLaunchKernelGGL(epipolar_bin_scan_kernel, dim3((unsigned)((n_work + 63) / 64)), dim3(256), 0, st,
-                       bd.n_src, bd.tiles, bd.blocks_per_src, cnt, tile_len);
-    hipLaunchKernelGGL(epipolar_bin_offsets_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_len, tile_off);
-    hipLaunchKernelGGL(epipolar_tile_order_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_len, order);
-    hipLaunchKernelGGL(epipolar_bin_fill_kernel<TS>, dim3(bin_blocks), dim3(kBinTokens),
-                       (size_t)(kBinTokens / kWave) * bd.tiles * sizeof(uint32_t), st, dm, xy, flags, cnt,
-                       tile_off, list);
+    if (phases & 1) {
+      hipLaunchKernelGGL(epipolar_bin_count_kernel<TS>, dim3(bin_blocks), dim3(kBinTokens),
+                         (size_t)bd.tiles * sizeof(uint32_t), st, dm, xy, flags, cnt);
+      hipLaunchKernelGGL(epipolar_bin_scan_kernel, dim3((unsigned)((n_work + 63) / 64)), dim3(256), 0, st,
+                         bd.n_src, bd.tiles, bd.blocks_per_src, cnt, tile_len);
+      hipLaunchKernelGGL(epipolar_bin_offsets_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_len, tile_off);
+      hipLaunchKernelGGL(epipolar_tile_order_kernel, dim3(1), dim3(1024), 0, st, n_work, tile_len, order);
+      hipLaunchKernelGGL(epipolar_bin_fill_kernel<TS>, dim3(bin_blocks), dim3(kBinTokens),
+                         (size_t)(kBinTokens / kWave) * bd.tiles * sizeof(uint32_t), st, dm, xy, flags, cnt,
+                         tile_off, list);
+    }
+    if (!(phases & 2)) return PS_OK;
     const size_t sm3 = (size_t)kDfWaves * tile_floats * sizeof(float);
 #define PS_TG(CPL)                                                                              \
   do {                                                                                          \

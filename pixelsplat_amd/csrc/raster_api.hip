@@ -411,7 +411,7 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
   if (dfmap) {
     Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
     if (int rc = launch_epipolar_feature_grad(to_dims(d), 1, xy_sample, flags, &qt, &attn, &dfbar,
-                                              &ds, dfmap, ray_boxes, nullptr, (hipStream_t)stream))
+                                              &ds, dfmap, ray_boxes, nullptr, 3, (hipStream_t)stream))
       return rc;
   }
   return check_launch();
@@ -426,7 +426,7 @@ int ps_epipolar_feature_grad(const PsEpipolarDesc* d, int32_t n_layers, const fl
     return PS_ERR_BAD_ARG;
   Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
   if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn,
-                                            dfbar, ds, dfmap, ray_boxes, nullptr,
+                                            dfbar, ds, dfmap, ray_boxes, nullptr, 3,
                                             (hipStream_t)stream))
     return rc;
   return check_launch();
@@ -456,7 +456,33 @@ int ps_epipolar_feature_grad_two_pass(const PsEpipolarDesc* d, int32_t n_layers,
     return PS_ERR_BAD_ARG;
   Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
   if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn,
-                                            dfbar, ds, dfmap, ray_boxes, token_grad,
+                                            dfbar, ds, dfmap, ray_boxes, token_grad, 3,
+                                            (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_epipolar_feature_bins(const PsEpipolarDesc* d, const float* xy_sample, const uint8_t* flags,
+                             uint32_t* ray_boxes, void* stream) {
+  if (!epi_ok(d) || !xy_sample || !flags || !ray_boxes) return PS_ERR_BAD_ARG;
+  Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
+  if (int rc = launch_epipolar_feature_grad(to_dims(d), 0, xy_sample, flags, nullptr, nullptr, nullptr,
+                                            nullptr, nullptr, ray_boxes, nullptr, 1, (hipStream_t)stream))
+    return rc;
+  return check_launch();
+}
+
+int ps_epipolar_feature_grad_binned(const PsEpipolarDesc* d, int32_t n_layers, const float* xy_sample,
+                                    const uint8_t* flags, const float* const* qt,
+                                    const float* const* attn, const float* const* dfbar,
+                                    const float* const* ds, float* dfmap, const uint32_t* ray_boxes,
+                                    float* token_grad, void* stream) {
+  if (!epi_ok(d) || !xy_sample || !flags || !qt || !attn || !dfbar || !ds || !dfmap || !ray_boxes ||
+      !token_grad)
+    return PS_ERR_BAD_ARG;
+  Scope sc(G_EPI_FGRAD, (hipStream_t)stream);
+  if (int rc = launch_epipolar_feature_grad(to_dims(d), n_layers, xy_sample, flags, qt, attn, dfbar, ds,
+                                            dfmap, const_cast<uint32_t*>(ray_boxes), token_grad, 2,
                                             (hipStream_t)stream))
     return rc;
   return check_launch();

@@ -183,7 +183,7 @@ int launch_epipolar_feature_grad(const AttnDims& dm, int n_layers, const float* 
                                  const uint8_t* flags, const float* const* qt,
                                  const float* const* attn, const float* const* dfbar,
                                  const float* const* ds, float* dfmap, uint32_t* boxes,
-                                 float* token_grad, hipStream_t st);
+                                 float* token_grad, int phases, hipStream_t st);
 int launch_adapter_views(int n_views, int sh_degree, int img_h, int img_w, const float* extrinsics,
                          const float* intrinsics, const double* conj, float* views,
                          hipStream_t st);

@@ -1,5 +1,5 @@
-// Tile kernels.  A 16x16 tile is four 8x8 QUADRANTS; a wave64 owns PS_FWD_QW of them in the forward
-// (default 2: two waves per tile) and all four in the backward, one pixel per lane and quadrant -- pixel
+// Tile kernels.  A 16x16 tile is four 8x8 QUADRANTS; a wave64 owns kFwdQW of them in the forward
+// (2: two waves per tile) and all four in the backward, one pixel per lane and quadrant -- pixel
 // k of lane l sits in quadrant k at (l & 7, l >> 3).  Each staged entry carries a 4-bit mask of the
 // quadrants its alpha >= 1/255 ellipse can reach, so the per-entry work is skipped per quadrant with
 // wave-uniform (scalar) branches.  There is no duplicated (tile, Gaussian) key list and no global
@@ -29,26 +29,24 @@
 #ifndef PS_ABLATE
 #define PS_ABLATE 0   // 1..3: timing experiments that drop part of a tile kernel's work (results invalid)
 #endif
-// Quadrants per forward wave: 4 = one wave per 16x16 tile (4 pixels per lane); 2 = two waves per tile
-// (top / bottom half, 2 pixels per lane); 1 = one wave per 8x8 quadrant.  Fewer quadrants per wave =
-// more, smaller tasks (7168 tile tasks on 4096 wave slots leave a launch tail that costs the
-// 4-quadrant kernel ~14 % at BASELINE configs[1]) and fewer registers (more waves per SIMD), paid for
-// with a refine pass per wave over the tile's whole list.  Results are identical by construction (a
-// pixel's walk does not depend on which wave owns it).  Measured (profiles/r3_forward_split_ab.txt,
-// configs[1]): 4 quadrants 0.93 ms, 2 quadrants 0.87 ms (5 or 6 waves per SIMD alike), 1 quadrant
-// 0.86-0.87 ms with four times the record gathers: 2 is the default.
-#ifndef PS_FWD_QW
-#define PS_FWD_QW 2
-#endif
+// Quadrants per forward wave.  2 = two waves per tile (top / bottom half, 2 pixels per lane): fewer
+// quadrants per wave = more, smaller tasks (7168 one-wave tile tasks on 4096 wave slots leave a launch
+// tail that costs ~14 % at BASELINE configs[1]) and fewer registers (more waves per SIMD), paid for with
+// a refine pass per wave over the tile's whole list.  Results are identical by construction (a pixel's
+// walk does not depend on which wave owns it).  Measured (profiles/r3_forward_split_ab.txt, configs[1]):
+// one wave per tile 0.93 ms, two 0.87 ms, four 0.86-0.87 ms with four times the record gathers.
 
 namespace ps {
 
-#ifndef PS_NO_FAST
-#define PS_NO_FAST 0        // 1: the backward never takes its short form (A/B of what it buys)
+#ifndef PS_FWD_FAST
+#define PS_FWD_FAST 1       // 0: the forward never takes its short form (A/B of what it buys)
 #endif
-constexpr int kFwdQW = PS_FWD_QW;
+#ifndef PS_FWD_WIN
+#define PS_FWD_WIN 8        // ring entries per stop-free window of the forward's short form
+#endif
+constexpr unsigned kFwdWin = PS_FWD_WIN;
+constexpr int kFwdQW = 2;
 constexpr int kFwdParts = 4 / kFwdQW;
-static_assert(kFwdQW == 1 || kFwdQW == 2 || kFwdQW == 4, "PS_FWD_QW must be 1, 2 or 4");
 constexpr int kBatch = 64;
 constexpr int kQB = 128;            // ring B capacity (>= 63 + 64), power of two
 constexpr int kWavesPerBlock = 4;      // forward: tiles (waves) per block
@@ -77,6 +75,12 @@ __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
   return v;
+}
+
+__device__ __forceinline__ float wave_max_f(float v) {     // wave-uniform result (all lanes)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return __builtin_amdgcn_readfirstlane(v);
 }
 
 // v_exp_f32: 2^x
@@ -202,10 +206,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   * the refine's two dependent global latencies (list -> record gather) are off the wave's critical
 //     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
 //     is refined and blended.
-#ifndef PS_FWD_MIN_WAVES
-#define PS_FWD_MIN_WAVES (PS_FWD_QW == 4 ? 4 : 5)   // waves per SIMD the register allocation aims at
+#ifndef PS_FWD_WAVES
+#define PS_FWD_WAVES 5      // waves per SIMD the forward's register allocation aims at
 #endif
-__global__ void __launch_bounds__(kWavesPerBlock* kWave, PS_FWD_MIN_WAVES)
+constexpr int kFwdMinWaves = PS_FWD_WAVES;
+__global__ void __launch_bounds__(kWavesPerBlock* kWave, kFwdMinWaves)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ tile_order,
                      const uint32_t* __restrict__ tile_ranges,
@@ -264,14 +269,21 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   float Ts[QW];
 #pragma unroll
   for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
-  // one ring entry against the (up to QW) quadrants of this wave it can reach
-  auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
+  // one ring entry against the (up to QW) quadrants of this wave it can reach.
+  // FAST (decided per 8 ring entries, see blend1): every entry of the window is plain (entry_is_plain:
+  // no sign test of the power, no alpha_max clamp) and NO pixel of the wave can stop inside the window
+  // (all live with T >= thr = t_min / (1 - om)^8, om the largest opacity staged so far: alpha <= opacity
+  // for a plain entry, so T (1 - alpha) stays >= t_min for 8 entries) -- then max(T, 0), the stop test
+  // and its three selects are no-ops and are not issued: 15 instead of 21 instructions per quadrant
+  // evaluation, the same bits.  Both forms are instantiations of one lambda on the same variables
+  // (compiler-scheduled; round 3's hand-scheduled asm forms lost).
+  auto process_entry = [&](auto fast_tag, const float4 q0, const float4 q1, const float4 q2) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const uint32_t hidx = __float_as_uint(q2.y);
 #if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
 #else
-    // (one quadrant per wave: every ring entry reaches it, no mask to test)
-    const uint32_t qm = QW == 1 ? 1u : __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #endif
 #pragma unroll
     for (int k = 0; k < QW; ++k) {
@@ -279,19 +291,31 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
         const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
         const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
         const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
-        const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
-        const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
-        const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-        float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
-        asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
-        const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
-        const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
-        const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
-        Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
-        C0[k] = fmaf(q1.z, wgt, C0[k]);
-        C1[k] = fmaf(q1.w, wgt, C1[k]);
-        C2[k] = fmaf(q2.x, wgt, C2[k]);
-        last[k] = (ok & !stop) ? hidx : last[k];
+        if (FAST) {
+          const float alpha = q1.y * fast_exp2(pw);
+          const bool ok = alpha >= alpha_min;
+          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+          const f32x2 tw = f32x2{Ts[k], Ts[k]} * f32x2{1.f - ale, ale};    // (T (1 - a), T a)
+          Ts[k] = tw.x;
+          C0[k] = fmaf(q1.z, tw.y, C0[k]);
+          C1[k] = fmaf(q1.w, tw.y, C1[k]);
+          C2[k] = fmaf(q2.x, tw.y, C2[k]);
+          last[k] = ok ? hidx : last[k];
+        } else {
+          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+          const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
+          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+          float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
+          asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
+          const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
+          const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
+          const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
+          Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
+          C0[k] = fmaf(q1.z, wgt, C0[k]);
+          C1[k] = fmaf(q1.w, wgt, C1[k]);
+          C2[k] = fmaf(q2.x, wgt, C2[k]);
+          last[k] = (ok & !stop) ? hidx : last[k];
+        }
       }
     }
   };
@@ -301,71 +325,130 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     for (int k = 0; k < QW; ++k) any |= Ts[k] > 0.f;
     return !__any(any);
   };
-  auto blend1 = [&](uint32_t m) {
+  // ring bookkeeping of the short form (wave-uniform): absolute ring index one past the last entry
+  // that is NOT plain (entries from there on are plain), the largest opacity staged so far and the
+  // stop-free threshold it implies for a window of kFwdWin entries
+  constexpr uint32_t kWin = kFwdWin;
+  uint32_t np_end = 0;
+  float om_run = 0.f, thr = t_min;
+  bool slow_for_good = !PS_FWD_FAST;   // some pixel fell below thr (or stopped): T only shrinks, thr only grows
+  // one blend call = up to kBatch ring entries in ONE form (each form is a loop nest of its own: with
+  // both forms in one loop body the compiler merges their results through copies, +4 v_mov per slow
+  // evaluation; with a switch per window the two nests exchange the whole pixel state through ~30
+  // copies per window).  Two entries per trip, each one's record read from LDS while the other is
+  // blended.  FAST: returns false at the first window that may not take the short form, with b_head
+  // at that window (nothing of it consumed).
+  auto blend1 = [&](auto fast_tag, uint32_t m) -> bool {
+    constexpr bool FAST = decltype(fast_tag)::value;
     uint32_t slot = b_head & (kQB - 1);
     float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-    for (uint32_t j = 0; j < m; j += 2) {
+    uint32_t j = 0;
+    bool ok = true;
+    for (; j < m; j += 2) {
+      if ((j & (kWin - 1)) == 0) {
+        if (FAST) {
+          bool low = false;
+#pragma unroll
+          for (int k = 0; k < QW; ++k) low |= !(Ts[k] >= thr);   // stopped (T < 0) / outside pixels too
+          if (__any(low)) { slow_for_good = true; ok = false; break; }
+          if (b_head + j < np_end) { ok = false; break; }
+        } else if (j != 0 && every_pixel_stopped()) {
+          all_done = true; j = m; break;
+        }
+      }
       slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
       const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-      process_entry(a0, a1, a2);
-      if (j + 1 >= m) break;
+      process_entry(fast_tag, a0, a1, a2);
+      if (j + 1 >= m) { j = m; break; }
       slot = (b_head + j + 2) & (kQB - 1);
       a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-      process_entry(b0, b1, b2);
-      if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
+      process_entry(fast_tag, b0, b1, b2);
     }
-    b_head += m;
+    if (!FAST && !all_done && every_pixel_stopped()) all_done = true;
+    b_head += j < m ? j : m;
     wave_lds_sync();
+    return ok;
   };
 
-  {
-    auto gather = [&](uint32_t id, float4& r0, float4& r1, float4& r2) {
-      const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
-      r0 = r[0]; r1 = r[1]; r2 = r[2];
-    };
-    auto idx_of = [&](uint32_t first) {
-      return first + (uint32_t)lane < l_count ? list[first + lane] : list[0];
-    };
-    float4 n0, n1, n2;
-    uint32_t id2 = 0;
-    if (l_count > 0) {
-      gather(idx_of(0), n0, n1, n2);
-      id2 = idx_of(kBatch);
+  auto gather = [&](uint32_t id, float4& r0, float4& r1, float4& r2) {
+    const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
+    r0 = r[0]; r1 = r[1]; r2 = r[2];
+  };
+  auto idx_of = [&](uint32_t first) {
+    return first + (uint32_t)lane < l_count ? list[first + lane] : list[0];
+  };
+  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+  uint32_t id2 = 0;
+  if (l_count > 0) {
+    gather(idx_of(0), n0, n1, n2);
+    id2 = idx_of(kBatch);
+  }
+  uint32_t first = 0;                  // next list entry to refine
+  // refine the batch of list entries [first, first + kBatch) into the ring
+  auto refine = [&]() {
+    const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
+    const float4 r0 = n0, r1 = n1, r2 = n2;
+    if (first + kBatch < l_count) {
+      gather(id2, n0, n1, n2);
+      id2 = idx_of(first + 2 * kBatch);
     }
-    for (uint32_t first = 0; first < l_count && !all_done; first += kBatch) {
-      const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
-      const float4 r0 = n0, r1 = n1, r2 = n2;
-      if (first + kBatch < l_count) {
-        gather(id2, n0, n1, n2);
-        id2 = idx_of(first + 2 * kBatch);
+    bool keep = false, not_plain = false;
+    float4 q0, q1, q2;
+    float opac = 0.f;
+    if ((uint32_t)lane < m) {
+      const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
+      const uint32_t qm = quadrant_mask_part<QW>(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0, q_first);
+      keep = qm != 0u;
+      q0 = make_float4(r0.x, r0.y, A, B);
+      q1 = make_float4(Cq, r1.y, r2.x, r2.y);
+      q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
+      not_plain = keep && !entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max);
+      opac = keep ? r1.y : 0.f;
+    }
+    const uint64_t mask = __ballot(keep);
+    if (keep) {
+      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
+      lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
+    }
+    if (!slow_for_good) {
+      const uint64_t npm = __ballot(not_plain);
+      if (npm) {     // ring index one past the batch's last entry that is not plain
+        const int hi = 63 - __builtin_clzll(npm);
+        np_end = b_tail + (uint32_t)__popcll(mask & ((2ull << hi) - 1ull));
       }
-      bool keep = false;
-      float4 q0, q1, q2;
-      if ((uint32_t)lane < m) {
-        const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
-        const uint32_t qm = QW == 4 ? quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0)
-                                    : quadrant_mask_part<QW>(r0.x, r0.y, A, B, Cq, r1.y, alpha_min,
-                                                             x0, y0, q_first);
-        keep = qm != 0u;
-        q0 = make_float4(r0.x, r0.y, A, B);
-        q1 = make_float4(Cq, r1.y, r2.x, r2.y);
-        q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
+      const float ob = wave_max_f(opac);          // (NaN / negative opacities are not plain)
+      if (ob > om_run) {
+        om_run = ob;
+        // (1 - om)^-kWin by log2 / exp2, rounded up; om -> 1 gives inf: no window is ever fast
+        thr = t_min * fast_exp2(-(float)kWin * __log2f(1.f - om_run)) * 1.0001f;
+        thr = thr >= t_min ? thr : 3.0e38f;       // NaN (om > 1): never
       }
-      const uint64_t mask = __ballot(keep);
-      if (keep) {
-        const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
-        lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
-      }
-      b_tail += (uint32_t)__popcll(mask);
-      wave_lds_sync();
-      // full batches while the list lasts, then whatever is left (ONE call site: the blend loop
-      // is instantiated once)
-      const bool last_batch = first + kBatch >= l_count;
-      while (!all_done && (b_tail - b_head >= (uint32_t)kBatch || (last_batch && b_tail != b_head))) {
+    }
+    b_tail += (uint32_t)__popcll(mask);
+    first += kBatch;
+    wave_lds_sync();
+  };
+  // The walk in one form: full blend calls while the list lasts, then whatever is left.  The FAST
+  // instance hands over at the first window that fails its test; the slow instance returns after ONE
+  // blend call unless the short form is out for good, so that a few non-plain entries cost one call.
+  bool finished = l_count == 0;
+  auto walk = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    for (;;) {
+      const bool refined_all = first >= l_count;
+      while (!all_done && (b_tail - b_head >= (uint32_t)kBatch || (refined_all && b_tail != b_head))) {
         const uint32_t have = b_tail - b_head;
-        blend1(have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
+        const bool ok = blend1(fast_tag, have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
+        if (FAST && !ok) return;
+        if (!FAST && !slow_for_good) return;
       }
+      if (all_done || refined_all) { finished = true; return; }
+      refine();
     }
+  };
+  while (!finished) {
+    if (!slow_for_good) walk(std::true_type{});
+    if (!finished) walk(std::false_type{});
   }
 #pragma unroll
   for (int k = 0; k < QW; ++k) T[k] = fabsf(Ts[k]);
@@ -390,10 +473,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   }
   // the tile's last contributor (informational since the backward derives it from n_contrib;
   // with several waves per tile only the one-wave-per-tile build writes it)
-  if (QW == 4) {
-    max_c = wave_max_u(max_c);
-    if (lane == 0) tile_end[tile_global] = max_c;
-  }
+  (void)max_c; (void)tile_end;
 }
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
@@ -563,7 +643,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     return (uint32_t)lane < top ? list[top - 1u - lane] : list[0];
   };
   uint32_t id_ahead = c_max > 0 ? idx_of(c_max) : 0u;
-  bool plain_run = true;                       // every entry in the ring is plain
+  uint32_t np_end = 0;     // absolute ring index one past the last entry that is NOT plain
   auto refine = [&](uint32_t top, uint32_t m) {
     bool keep = false, not_plain = false;
     float4 q0, q1, q2;
@@ -596,9 +676,14 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                        __uint_as_float(target));
       not_plain = keep && !entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max);
     }
-    if (b_tail == b_head) plain_run = true;      // running flag over the ring, reset when it is empty
-    plain_run = plain_run && !__any(not_plain);
     const uint64_t mask = __ballot(keep);
+    {
+      const uint64_t npm = __ballot(not_plain);
+      if (npm) {
+        const int hi = 63 - __builtin_clzll(npm);
+        np_end = b_tail + (uint32_t)__popcll(mask & ((2ull << hi) - 1ull));
+      }
+    }
     if (keep) {
       const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
       lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
@@ -759,14 +844,14 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     nc_min = ~wave_max_u(~n);
   }
   auto blend = [&](uint32_t m) {
-    const bool ring_plain = plain_run && !PS_NO_FAST;
     for (uint32_t base = 0; base < m; base += kStage) {
       const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
       // the batch's first entry has its highest list index (the walk runs back to front)
       const uint32_t slot = (b_head + base) & (kQB - 1);
       const uint32_t top_h =
           __builtin_amdgcn_readfirstlane(__float_as_uint(lds.rec[slot][2].y));
-      if (ring_plain && top_h <= nc_min) stage_batch(std::true_type{}, base, cnt);
+      // short form: every entry from here to the ring's tail is plain and inside every pixel's walk
+      if (b_head + base >= np_end && top_h <= nc_min) stage_batch(std::true_type{}, base, cnt);
       else stage_batch(std::false_type{}, base, cnt);
     }
     b_head += m;

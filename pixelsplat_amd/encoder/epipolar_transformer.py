@@ -242,6 +242,9 @@ class EpipolarTransformer(nn.Module):
         kv = None
         folds = self.fold_layers(view_emb) if features.is_cuda else [None] * len(self.transformer.layers)
         grad_batch = FeatureGradBatch()     # the layers' feature-map gradients share one scatter
+        # the map as the attention layers see it: its gradient is produced on a side stream and only
+        # waited for where autograd hands it on; the query tokens `x` come from the original map
+        fmap_kv = grad_batch.attach(fmap)
         for (attn, ff), folded in zip(self.transformer.layers, folds):
             a = attn.fn
             if len(a.attend._forward_hooks) > 0:
@@ -254,7 +257,7 @@ class EpipolarTransformer(nn.Module):
                     kv = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, -1, c)
                 x = attn(x, z=kv) + x
             else:
-                x = self.fused_block(attn, x, fmap, geo, view_emb, folded, grad_batch)
+                x = self.fused_block(attn, x, fmap_kv, geo, view_emb, folded, grad_batch)
             x = ff(x, b=b, v=v, h=h, w=w) + x
         features = x.reshape(b, v, h, w, c).permute(0, 1, 4, 2, 3)
 

@@ -245,6 +245,37 @@ def _pad4(n: int) -> int:
 TWO_PASS_FEATURE_GRAD = _os.environ.get("PS_DFMAP_TWO_PASS", "1") != "0"
 
 
+# The feature-map gradient (0.65 ms of HBM-bound kernels at BASELINE configs[1]) runs on a side stream,
+# under the first layer's weight-gradient / input-gradient GEMMs and LayerNorm backward (matrix-pipe
+# bound), and its token lists -- geometry only -- are binned there while the LAST layer's backward still
+# runs.  PS_DFMAP_OVERLAP=0: everything inline on the caller's stream.
+OVERLAP_FEATURE_GRAD = _os.environ.get("PS_DFMAP_OVERLAP", "1") != "0"
+_FGRAD_STREAMS: dict = {}
+
+
+def _fgrad_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _FGRAD_STREAMS:
+        _FGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _FGRAD_STREAMS[key]
+
+
+class _JoinFeatureGrad(torch.autograd.Function):
+    """Identity on the feature map as the attention layers see it.  Its backward runs after theirs
+    (it is their only consumer of that gradient) and makes the caller's stream wait for the deferred
+    feature-map gradient that `FeatureGradBatch.flush` launched on the side stream."""
+
+    @staticmethod
+    def forward(ctx, fmap, batch):
+        ctx.batch = batch
+        return fmap.view_as(fmap)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.batch.join()
+        return g, None
+
+
 class FeatureGradBatch:
     """Defers the feature-map gradients of attention layers that share one geometry and one
     feature map (the layers of an EpipolarTransformer) so that they are scattered in ONE pass
@@ -252,13 +283,34 @@ class FeatureGradBatch:
     backward in reverse, each parks its coefficients here, and the first-registered layer --
     whose backward is necessarily the last -- flushes and returns the summed gradient.  One
     batch per forward pass; the layers must be chained (each feeds the next), as in
-    Transformer.forward (transformer.py:67-71)."""
+    Transformer.forward (transformer.py:67-71).
+
+    `attach(fmap)` (optional) returns the map the layers should be given: with it the flush runs on a
+    side stream and the returned gradient is only waited for where autograd hands it on (the query
+    tokens must be taken from the ORIGINAL map, so that nothing is accumulated into the gradient
+    before the wait)."""
 
     MAX_PER_LAUNCH = 2
 
-    def __init__(self):
+    def __init__(self, overlap: bool | None = None):
         self.registered = 0
         self.pending = []
+        self.overlap = OVERLAP_FEATURE_GRAD if overlap is None else overlap
+        self._attached = False
+        self._done = None        # event: the side stream finished the flush
+        self._keep = None        # tensors the side stream is using until then
+        self._bins = None        # (token lists, scratch words) binned ahead of the flush
+
+    def attach(self, fmap: Tensor) -> Tensor:
+        if not (self.overlap and fmap.is_cuda and fmap.requires_grad and torch.is_grad_enabled()):
+            return fmap
+        self._attached = True
+        return _JoinFeatureGrad.apply(fmap, self)
+
+    def join(self) -> None:
+        if self._done is not None:
+            torch.cuda.current_stream().wait_event(self._done)
+        self._done = self._keep = None
 
     def register(self) -> int:
         if self.pending:
@@ -266,7 +318,24 @@ class FeatureGradBatch:
         self.registered += 1
         return self.registered - 1
 
-    def park(self, qin, attn, dout, ds):
+    def _use_side(self, t: Tensor) -> bool:
+        return self.overlap and self._attached and t.is_cuda
+
+    def park(self, qin, attn, dout, ds, desc=None, xy=None, flags=None):
+        if (not self.pending and desc is not None and self._use_side(xy) and TWO_PASS_FEATURE_GRAD
+                and self._bins is None and self.registered > 1):
+            # first backward of the batch (the last layer's): the token lists depend on the sampling
+            # geometry alone -- bin them on the side stream now, under the layers' backward
+            lib = _lib.load()
+            side, main = _fgrad_stream(xy.device), torch.cuda.current_stream()
+            words = max(flags.numel(), lib.ps_epipolar_ray_box_words(C.byref(desc)))
+            boxes = torch.empty((words,), dtype=torch.int32, device=xy.device)
+            boxes.record_stream(side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.check(lib.ps_epipolar_feature_bins(C.byref(desc), _p(xy), _p(flags), _p(boxes),
+                                                        _stream()), "ps_epipolar_feature_bins")
+            self._bins = boxes
         self.pending.append((qin, attn, dout, ds))
 
     def __del__(self):
@@ -282,8 +351,11 @@ class FeatureGradBatch:
     def flush(self, desc, fmap, xy, flags, c):
         lib = _lib.load()
         total = None
-        boxes = torch.empty((max(flags.numel(), lib.ps_epipolar_ray_box_words(C.byref(desc))),),
-                            dtype=torch.int32, device=fmap.device)
+        prebinned = self._bins is not None
+        boxes = self._bins if prebinned else torch.empty(
+            (max(flags.numel(), lib.ps_epipolar_ray_box_words(C.byref(desc))),),
+            dtype=torch.int32, device=fmap.device)
+        self._bins = None
         # two-pass scheme: token gradients once (d(kv) of the reference: b v (v-1) h w s c floats of
         # caller-owned scratch, 0.94 GB at BASELINE configs[1], 1.6 GB at configs[3] -- it sits in
         # the backward-time peak, INTEGRATION.md "memory"), then the tile gather.  One scratch for
@@ -298,22 +370,42 @@ class FeatureGradBatch:
                     scratch = torch.empty((need,), dtype=torch.float32, device=fmap.device)
                 except torch.OutOfMemoryError:
                     scratch = None
+        use_side = self._use_side(fmap)
+        groups = []
         while self.pending:
-            group, self.pending = (self.pending[:self.MAX_PER_LAUNCH],
-                                   self.pending[self.MAX_PER_LAUNCH:])
-            n = len(group)
-            arr = lambda k, off=0: (C.c_void_p * n)(*[t[k].data_ptr() + 4 * off for t in group])
-            dfmap = torch.empty_like(fmap)
-            if scratch is not None:
-                _lib.check(lib.ps_epipolar_feature_grad_two_pass(
-                    C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
-                    _p(dfmap), _p(boxes), _p(scratch), _stream()),
-                    "ps_epipolar_feature_grad_two_pass")
-            else:
-                _lib.check(lib.ps_epipolar_feature_grad(
-                    C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
-                    _p(dfmap), _p(boxes), _stream()), "ps_epipolar_feature_grad")
-            total = dfmap if total is None else total + dfmap
+            groups.append(self.pending[:self.MAX_PER_LAUNCH])
+            self.pending = self.pending[self.MAX_PER_LAUNCH:]
+        dfmaps = [torch.empty_like(fmap) for _ in groups]      # (allocated on the caller's stream)
+        if use_side:
+            side = _fgrad_stream(fmap.device)
+            side.wait_stream(torch.cuda.current_stream())
+        elif prebinned:     # lists were binned on the side stream: the caller's stream needs them
+            torch.cuda.current_stream().wait_stream(_fgrad_stream(fmap.device))
+        with torch.cuda.stream(side) if use_side else _nullcontext():
+            for gi, (group, dfmap) in enumerate(zip(groups, dfmaps)):
+                n = len(group)
+                arr = lambda k, off=0: (C.c_void_p * n)(*[t[k].data_ptr() + 4 * off for t in group])
+                if scratch is not None and prebinned:
+                    _lib.check(lib.ps_epipolar_feature_grad_binned(
+                        C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
+                        _p(dfmap), _p(boxes), _p(scratch), _stream()),
+                        "ps_epipolar_feature_grad_binned")
+                elif scratch is not None:
+                    _lib.check(lib.ps_epipolar_feature_grad_two_pass(
+                        C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
+                        _p(dfmap), _p(boxes), _p(scratch), _stream()),
+                        "ps_epipolar_feature_grad_two_pass")
+                    prebinned = True       # (the lists of this geometry are in `boxes` now)
+                else:
+                    _lib.check(lib.ps_epipolar_feature_grad(
+                        C.byref(desc), C.c_int32(n), _p(xy), _p(flags), arr(0), arr(1), arr(2), arr(3),
+                        _p(dfmap), _p(boxes), _stream()), "ps_epipolar_feature_grad")
+                total = dfmap if total is None else total + dfmap
+            if use_side:
+                self._done = torch.cuda.Event()
+                self._done.record(side)
+                # alive until the caller's stream has waited (join): the side stream is still reading
+                self._keep = (groups, dfmaps, boxes, scratch, total)
         return total
 
 
@@ -388,7 +480,7 @@ class _FusedEpipolarAttention(torch.autograd.Function):
             _stream()), "ps_epipolar_attention_backward")
         if deferred:
             # parked until the first layer of the batch (whose backward runs last) flushes
-            ctx.batch.park(qin, attn, dout, ds)
+            ctx.batch.park(qin, attn, dout, ds, d, xy, flags)
             if ctx.batch_index == 0:
                 dfmap = ctx.batch.flush(d, fmap, xy, flags, c)
         return (None, None, None, dfmap, None, None, None, dqin, None)

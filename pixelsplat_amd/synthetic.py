@@ -88,10 +88,26 @@ def _quat_to_matrix(q: Tensor, eps: float = 1e-8) -> Tensor:
     return o.reshape(q.shape[:-1] + (3, 3))
 
 
+# Scene distributions ("a trained model keeps most in frame ... Measure, don't assume").
+# Every variant draws the SAME random numbers in the same order as "survey" and only maps them
+# differently, so the cameras, pixel jitter and colours of a seed are shared across scenes.
+#   survey  the SURVEY 8d recipe: depth uniform in disparity over [near, far] (most Gaussians close to the
+#           context cameras: ~40 % of (target view, Gaussian) pairs in frame), opacity U(0, 1/3)
+#   dense   depth restricted to the far part of the disparity range, where the parallax between the
+#           context and the in-between target cameras is small: >= 80 % of the pairs in frame (D/G >= 2)
+#   opaque  opacity U(0.5, 1) (encoder_epipolar.py:170 after training): pixels saturate and stop early
+#   large   scale multiplier x 3 (gaussian_adapter.py:62-69 at the top of its range): most Gaussians
+#           cover more than 4 tiles -> the tile backward's atomic path
+SCENES = ("survey", "dense", "opaque", "large")
+_DENSE_U_MIN = 0.85
+
+
 def make_gaussians(ctx: Cameras, hw: tuple[int, int], gen: torch.Generator,
-                   per_pixel: int = 3, sh_degree: int = 4) -> SceneGaussians:
+                   per_pixel: int = 3, sh_degree: int = 4, scene: str = "survey") -> SceneGaussians:
     """G = v_ctx * h * w * per_pixel Gaussians per scene, footprint statistics as an
-    untrained pixelSplat encoder would emit them."""
+    untrained pixelSplat encoder would emit them (`scene`: see SCENES)."""
+    if scene not in SCENES:
+        raise ValueError(f"scene must be one of {SCENES}")
     h, w = hw
     b, v = ctx.near.shape
     n = h * w * per_pixel
@@ -102,6 +118,8 @@ def make_gaussians(ctx: Cameras, hw: tuple[int, int], gen: torch.Generator,
     xy = (xy + jitter).reshape(b, v, n, 2)
 
     u = torch.rand((b, v, n), generator=gen)
+    if scene == "dense":
+        u = _DENSE_U_MIN + (1 - _DENSE_U_MIN) * u
     near, far = ctx.near[..., None], ctx.far[..., None]
     eps = 1e-10
     disp_near, disp_far = 1 / (near + eps), 1 / (far + eps)
@@ -118,7 +136,7 @@ def make_gaussians(ctx: Cameras, hw: tuple[int, int], gen: torch.Generator,
 
     fx = ctx.intrinsics[..., 0, 0][..., None]
     fy = ctx.intrinsics[..., 1, 1][..., None]
-    mult = 0.1 * (1 / (w * fx) + 1 / (h * fy))
+    mult = (0.3 if scene == "large" else 0.1) * (1 / (w * fx) + 1 / (h * fy))
     raw = torch.randn((b, v, n, 3), generator=gen)
     scales = (0.5 + 14.5 * raw.sigmoid()) * depth[..., None] * mult[..., None]
     q = torch.randn((b, v, n, 4), generator=gen)
@@ -133,7 +151,8 @@ def make_gaussians(ctx: Cameras, hw: tuple[int, int], gen: torch.Generator,
     for deg in range(1, sh_degree + 1):
         mask[deg ** 2:(deg + 1) ** 2] = 0.1 * 0.25 ** deg
     sh = torch.randn((b, v, n, 3, d_sh), generator=gen) * mask
-    opacity = torch.rand((b, v, n), generator=gen) / per_pixel
+    opacity = torch.rand((b, v, n), generator=gen)
+    opacity = 0.5 + 0.5 * opacity if scene == "opaque" else opacity / per_pixel
 
     return SceneGaussians(
         means.reshape(b, v * n, 3).contiguous(),
@@ -144,10 +163,10 @@ def make_gaussians(ctx: Cameras, hw: tuple[int, int], gen: torch.Generator,
 
 
 def make_workload(b: int, hw: tuple[int, int], v_ctx: int = 2, v_tgt: int = 4, seed: int = 0,
-                  per_pixel: int = 3, sh_degree: int = 4):
+                  per_pixel: int = 3, sh_degree: int = 4, scene: str = "survey"):
     """(context cameras, target cameras, scene Gaussians, target images) on CPU, fp32."""
     gen = torch.Generator().manual_seed(seed)
     ctx, tgt = make_cameras(b, v_ctx, v_tgt, hw, gen)
-    gaussians = make_gaussians(ctx, hw, gen, per_pixel, sh_degree)
+    gaussians = make_gaussians(ctx, hw, gen, per_pixel, sh_degree, scene)
     target = torch.rand((b, v_tgt, 3, hw[0], hw[1]), generator=gen)
     return ctx, tgt, gaussians, target

@@ -32,16 +32,18 @@ IMG_TOL = 1e-4
 GRAD_TOL = 5e-5
 
 
-def _run_config(name, dev, gemm_note=None):
+def _run_config(name, dev, gemm_note=None, scene="survey", marked_limit=0.002):
     from pixelsplat_amd.decoder import camera_setup, render_cuda
     from pixelsplat_amd.raster import export_bins, state_views
 
     kw, vp_ref = reference_cameras(name)
     hw, v = kw["hw"], kw["v_tgt"]
-    ctx, tgt, g, _ = make_workload(kw["b"], hw, v_ctx=kw["v_ctx"], v_tgt=v, seed=kw["seed"])
+    ctx, tgt, g, _ = make_workload(kw["b"], hw, v_ctx=kw["v_ctx"], v_tgt=v, seed=kw["seed"], scene=scene)
     G = g.means.shape[1]
     V = kw["b"] * v
     assert vp_ref.shape == (V, 48)
+    if scene != "survey":
+        name = f"{name}/{scene}"      # (the scene variants share the cameras of their seed)
     ext = tgt.extrinsics.reshape(V, 4, 4).to(dev)
     intr = tgt.intrinsics.reshape(V, 3, 3).to(dev)
     near, far = tgt.near.reshape(V).to(dev), tgt.far.reshape(V).to(dev)
@@ -67,13 +69,18 @@ def _run_config(name, dev, gemm_note=None):
 
     rng = np.random.default_rng(kw["seed"])
     dL = rng.normal(size=(V, 3) + hw).astype(np.float32)
-    states, stats = [], dict(marked=0, pixels=0, linf=0.0, D=0, visible=0, flipped=0, unexplained=0)
+    states, stats = [], dict(marked=0, pixels=0, linf=0.0, D=0, visible=0, flipped=0, unexplained=0,
+                             large=0, blended=0, evaluated=0)
     for vi in range(V):
         st = R.forward(H=hw[0], W=hw[1],
                        **oracle_view_inputs(g, tgt, vi // v, vi % v, view_params=vp_ref[vi]))
         states.append(st)
         stats["D"] += st.num_rendered
         stats["visible"] += int((st.radii > 0).sum())
+        stats["large"] += int((st.tiles_touched > 4).sum())      # pairs on the backward's atomic path
+        ev, bl = R.blend_stats(st)
+        stats["evaluated"] += ev
+        stats["blended"] += bl
         assert np.array_equal(radii[vi], st.radii), f"{name}: radii of view {vi}"
         cnt = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
         assert np.array_equal(counts[vi], cnt), f"{name}: tile counts of view {vi}"
@@ -99,7 +106,7 @@ def _run_config(name, dev, gemm_note=None):
         stats["unexplained"] += ex["unexplained"]
         assert ex["unexplained"] == 0, (name, vi, ex)
         dL[vi][:, amb] = 0.0
-    assert stats["marked"] < 0.002 * stats["pixels"], stats
+    assert stats["marked"] < marked_limit * stats["pixels"], stats
 
     # backward: every gradient tensor of EVERY scene against the oracle, summed over the scene's views
     B = kw["b"]
@@ -128,7 +135,8 @@ def _run_config(name, dev, gemm_note=None):
             e = np.abs(a[si] - r[si]).max() / max(np.abs(r[si]).max(), 1e-30)
             stats["grad_" + k] = max(stats.get("grad_" + k, 0.0), float(e))
             assert e < GRAD_TOL, f"{name}: scene {si}: d{k}: {e:.3e} of max"
-    print(f"\n[{name}] G={G} V={V} D={stats['D']} visible={stats['visible']} "
+    print(f"\n[{name}] G={G} V={V} D={stats['D']} visible={stats['visible']} >4-tile pairs={stats['large']} "
+          f"blended={stats['blended']} "
           f"marked={stats['marked']}/{stats['pixels']} (flipped {stats['flipped']}, unexplained "
           f"{stats['unexplained']}) linf_unmarked={stats['linf']:.2e} "
           + " ".join(f"{k}={stats[k]:.1e}" for k in stats if k.startswith("grad_"))
@@ -172,6 +180,30 @@ def test_config4_512(gpu_device):
     """BASELINE configs[4]: 512x512, G = 1 572 864 per scene, 1024 tiles per view (the
     tile-sort / list-length stress configuration)."""
     _run_config("c5_512", gpu_device)
+
+
+# ---- other Gaussian distributions at the configs[1] geometry (VERDICT r3 next #3): the design's own weak
+# points -- long lists with early termination, opaque surfaces, the > 4-tile atomic path -- held to the same
+# bars as the survey scene: bins bit-exact, image / final_T / n_contrib, all four gradients.
+def test_scene_dense_256(gpu_device):
+    """`dense`: 87 % of the (view, Gaussian) pairs in frame, D / (G V) = 2.8, pixels stop at ~47 % of
+    their tile's list."""
+    st = _run_config("c2_256", gpu_device, scene="dense")
+    assert st["visible"] > 0.8 * 4 * 393216 and st["D"] > 2 * 4 * 393216
+
+
+def test_scene_opaque_256(gpu_device):
+    """`opaque`: opacity U(0.5, 1) -- every pixel terminates early (median at 23 % of its list), entries
+    over the alpha_max clamp, the blend kernels' long forms."""
+    st = _run_config("c2_256", gpu_device, scene="opaque")
+    assert st["blended"] < 0.5 * 8740560 * 4
+
+
+def test_scene_large_256(gpu_device):
+    """`large`: scales x 3 -- 87 % of the visible pairs cover more than 4 tiles: the tile backward's
+    float-atomic accumulation instead of private slots (sum order not fixed: same 5e-5 bar)."""
+    st = _run_config("c2_256", gpu_device, scene="large")
+    assert st["large"] > 0.8 * st["visible"]
 
 
 def test_config1_256_batch7_equals_seven_single_scene_launches(gpu_device):
