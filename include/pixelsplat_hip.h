@@ -109,6 +109,9 @@ typedef struct PsRasterStateLayout {
   size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
   size_t tile_order;  /* uint32[V*T]: (view,tile) ids, longest list first (launch order)      */
   size_t clamp_bits;  /* uint8[N]: bit c set = SH colour channel c was clamped at 0 (visible entries) */
+  size_t checkpoint;  /* float[V][T][4][64][4]: per pixel (quadrant, lane) of a tile whose list is split in two
+                         for the backward: transmittance after the list's first half and the colour composited
+                         BEHIND it, divided by that transmittance (forward -> backward)             */
   size_t total;
 } PsRasterStateLayout;
 

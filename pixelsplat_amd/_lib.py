@@ -36,7 +36,7 @@ class PsRasterDesc(C.Structure):
 class PsRasterStateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "records", "rects", "sorted_idx", "sorted_rect", "n_vis", "final_T", "n_contrib",
-        "tile_end", "tile_ranges", "num_rendered", "tile_order", "clamp_bits",
+        "tile_end", "tile_ranges", "num_rendered", "tile_order", "clamp_bits", "checkpoint",
         "total")]
 
 

@@ -18,6 +18,16 @@ constexpr int kInvSlots = 4;            // Gaussians touching <= 4 tiles use slo
 // records[7] of a Gaussian touching <= kInvSlots tiles: bit 31 | (rect width - 1) << 29 |
 // ymin << 15 | xmin (tile units); 0 for larger rects (and for tile grids over 16383 rows)
 constexpr uint32_t kSmallFlag = 0x80000000u;
+// A tile list of at least kSplitMin entries is walked by the backward as TWO tasks: entries above the
+// split point (a multiple of the refine batch) and entries up to it; the forward leaves every pixel's
+// state at the split point in state.checkpoint (raster_tiles.hip).  0 = not split.
+#ifndef PS_SPLIT_MIN
+#define PS_SPLIT_MIN 256        // (A/B: -DPS_SPLIT_MIN=0x7fffffff never splits)
+#endif
+constexpr uint32_t kSplitMin = PS_SPLIT_MIN;
+__host__ __device__ inline uint32_t split_point(uint32_t l_count) {
+  return l_count >= kSplitMin ? ((l_count >> 1) & ~63u) : 0u;
+}
 
 // sort geometry
 constexpr int kSortThreads = 1024;      // 16 waves x 4 items: the per-wave ranking chain is the
@@ -100,6 +110,7 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.num_rendered = o; o = align_up(o + 8);
   s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
   s.clamp_bits = o; o = align_up(o + m.N);
+  s.checkpoint = o; o = align_up(o + (size_t)m.V * m.tiles * kTile * kTile * 16);
   s.total = o;
   return s;
 }
@@ -127,14 +138,14 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* tile_order, const uint32_t* tile_ranges,
                           const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
-                          float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
+                          float* final_T, uint32_t* n_contrib, float4* checkpoint,
                           hipStream_t st);
 
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            const uint32_t* tile_order, const uint32_t* tile_ranges,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
-                           const uint32_t* n_contrib, const uint32_t* tile_end,
+                           const uint32_t* n_contrib, const float4* checkpoint,
                            const float* dL_dcolor, float* grad2d, float* tile_grads,
                            hipStream_t st);
 

@@ -38,13 +38,6 @@
 
 namespace ps {
 
-#ifndef PS_FWD_FAST
-#define PS_FWD_FAST 1       // 0: the forward never takes its short form (A/B of what it buys)
-#endif
-#ifndef PS_FWD_WIN
-#define PS_FWD_WIN 8        // ring entries per stop-free window of the forward's short form
-#endif
-constexpr unsigned kFwdWin = PS_FWD_WIN;
 constexpr int kFwdQW = 2;
 constexpr int kFwdParts = 4 / kFwdQW;
 constexpr int kBatch = 64;
@@ -75,12 +68,6 @@ __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
   return v;
-}
-
-__device__ __forceinline__ float wave_max_f(float v) {     // wave-uniform result (all lanes)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return __builtin_amdgcn_readfirstlane(v);
 }
 
 // v_exp_f32: 2^x
@@ -207,7 +194,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
 //     is refined and blended.
 #ifndef PS_FWD_WAVES
-#define PS_FWD_WAVES 5      // waves per SIMD the forward's register allocation aims at
+#define PS_FWD_WAVES 6      // waves per SIMD the forward's register allocation aims at (80 VGPRs; the 16 spilled ones are only live outside the walk)
 #endif
 constexpr int kFwdMinWaves = PS_FWD_WAVES;
 __global__ void __launch_bounds__(kWavesPerBlock* kWave, kFwdMinWaves)
@@ -217,7 +204,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ point_list, uint32_t capacity,
                      const float* __restrict__ view_params, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                     uint32_t* __restrict__ tile_end) {
+                     float4* __restrict__ checkpoint) {
   constexpr int QW = kFwdQW;          // quadrants (= pixels per lane) of this wave
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int G = d.n_gaussians, H = d.height, W = d.width;
@@ -244,6 +231,13 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   l_start = __builtin_amdgcn_readfirstlane(l_start);
   l_count = __builtin_amdgcn_readfirstlane(l_count);
   const uint32_t* list = point_list + l_start;
+  // the backward walks a long list as two tasks (raster_common.h: split_point): this wave leaves its
+  // pixels' state at the split point -- T and the accumulated colour, rewritten in the epilogue as the
+  // colour composited BEHIND the split point over that T, which is what the front task starts from
+  const uint32_t ck_at = split_point(l_count);
+  // [tile][quadrant][lane]; the address is rebuilt where it is used (two registers less across the walk)
+  auto ck_ptr = [&]() { return checkpoint + ((size_t)tile_global * 4 + q_first) * kWave + lane; };
+  bool ck_written = false;
 
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
   int px[QW], py[QW]; float pxf[QW], pyf[QW]; bool live[QW];
@@ -269,16 +263,8 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   float Ts[QW];
 #pragma unroll
   for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
-  // one ring entry against the (up to QW) quadrants of this wave it can reach.
-  // FAST (decided per 8 ring entries, see blend1): every entry of the window is plain (entry_is_plain:
-  // no sign test of the power, no alpha_max clamp) and NO pixel of the wave can stop inside the window
-  // (all live with T >= thr = t_min / (1 - om)^8, om the largest opacity staged so far: alpha <= opacity
-  // for a plain entry, so T (1 - alpha) stays >= t_min for 8 entries) -- then max(T, 0), the stop test
-  // and its three selects are no-ops and are not issued: 15 instead of 21 instructions per quadrant
-  // evaluation, the same bits.  Both forms are instantiations of one lambda on the same variables
-  // (compiler-scheduled; round 3's hand-scheduled asm forms lost).
-  auto process_entry = [&](auto fast_tag, const float4 q0, const float4 q1, const float4 q2) {
-    constexpr bool FAST = decltype(fast_tag)::value;
+  // one ring entry against the (up to QW) quadrants of this wave it can reach
+  auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
     const uint32_t hidx = __float_as_uint(q2.y);
 #if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
@@ -291,31 +277,19 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
         const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};      // (dx, dy)
         const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};          // (B dy, C dy)
         const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);  // power * log2(e)
-        if (FAST) {
-          const float alpha = q1.y * fast_exp2(pw);
-          const bool ok = alpha >= alpha_min;
-          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-          const f32x2 tw = f32x2{Ts[k], Ts[k]} * f32x2{1.f - ale, ale};    // (T (1 - a), T a)
-          Ts[k] = tw.x;
-          C0[k] = fmaf(q1.z, tw.y, C0[k]);
-          C1[k] = fmaf(q1.w, tw.y, C1[k]);
-          C2[k] = fmaf(q2.x, tw.y, C2[k]);
-          last[k] = ok ? hidx : last[k];
-        } else {
-          const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
-          const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
-          const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
-          float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
-          asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
-          const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
-          const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
-          const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
-          Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
-          C0[k] = fmaf(q1.z, wgt, C0[k]);
-          C1[k] = fmaf(q1.w, wgt, C1[k]);
-          C2[k] = fmaf(q2.x, wgt, C2[k]);
-          last[k] = (ok & !stop) ? hidx : last[k];
-        }
+        const float alpha = fminf(alpha_max, q1.y * fast_exp2(pw));
+        const bool ok = (pw <= 0.f) & (alpha >= alpha_min);
+        const float ale = ok ? alpha : 0.f;          // 0 => every update below is a no-op
+        float Tp;                                    // max(T, 0): 0 for a stopped pixel (one
+        asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[k]));   // instruction; fmaxf adds a canonicalize)
+        const f32x2 tw = f32x2{Tp, Tp} * f32x2{1.f - ale, ale};          // (T (1 - a), T a)
+        const bool stop = tw.x < t_min;              // a live pixel can only stop when ale > 0;
+        const float wgt = stop ? 0.f : tw.y;         // a stopped one always "stops" again
+        Ts[k] = stop ? -fabsf(Ts[k]) : tw.x;
+        C0[k] = fmaf(q1.z, wgt, C0[k]);
+        C1[k] = fmaf(q1.w, wgt, C1[k]);
+        C2[k] = fmaf(q2.x, wgt, C2[k]);
+        last[k] = (ok & !stop) ? hidx : last[k];
       }
     }
   };
@@ -325,57 +299,37 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     for (int k = 0; k < QW; ++k) any |= Ts[k] > 0.f;
     return !__any(any);
   };
-  // ring bookkeeping of the short form (wave-uniform): absolute ring index one past the last entry
-  // that is NOT plain (entries from there on are plain), the largest opacity staged so far and the
-  // stop-free threshold it implies for a window of kFwdWin entries
-  constexpr uint32_t kWin = kFwdWin;
-  uint32_t np_end = 0;
-  float om_run = 0.f, thr = t_min;
-  bool slow_for_good = !PS_FWD_FAST;   // some pixel fell below thr (or stopped): T only shrinks, thr only grows
-  // one blend call = up to kBatch ring entries in ONE form (each form is a loop nest of its own: with
-  // both forms in one loop body the compiler merges their results through copies, +4 v_mov per slow
-  // evaluation; with a switch per window the two nests exchange the whole pixel state through ~30
-  // copies per window).  Two entries per trip, each one's record read from LDS while the other is
-  // blended.  FAST: returns false at the first window that may not take the short form, with b_head
-  // at that window (nothing of it consumed).
-  auto blend1 = [&](auto fast_tag, uint32_t m) -> bool {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    uint32_t slot = b_head & (kQB - 1);
+  // m ring entries, two per trip, each one's record read from LDS while the other is blended; "is every
+  // pixel finished?" is asked once per 8 entries.  The ring cursors are wave-uniform by construction
+  // (sums of ballot popcounts) and the compiler is TOLD so (readfirstlane): left to its own analysis it
+  // keeps them in vector registers and compiles every loop bounded by them as divergent control flow
+  // (s_and_saveexec chains): tiles_forward 0.86 -> 0.82 ms at BASELINE configs[1]
+  // (profiles/r4_forward_forms_ab.txt).
+  auto blend1 = [&](uint32_t m) {
+    m = __builtin_amdgcn_readfirstlane(m);
+    const uint32_t bh = __builtin_amdgcn_readfirstlane(b_head);
+    uint32_t slot = bh & (kQB - 1);
     float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-    uint32_t j = 0;
-    bool ok = true;
-    for (; j < m; j += 2) {
-      if ((j & (kWin - 1)) == 0) {
-        if (FAST) {
-          bool low = false;
-#pragma unroll
-          for (int k = 0; k < QW; ++k) low |= !(Ts[k] >= thr);   // stopped (T < 0) / outside pixels too
-          if (__any(low)) { slow_for_good = true; ok = false; break; }
-          if (b_head + j < np_end) { ok = false; break; }
-        } else if (j != 0 && every_pixel_stopped()) {
-          all_done = true; j = m; break;
-        }
-      }
-      slot = (b_head + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
+    for (uint32_t j = 0; j < m; j += 2) {
+      slot = (bh + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
       const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-      process_entry(fast_tag, a0, a1, a2);
-      if (j + 1 >= m) { j = m; break; }
-      slot = (b_head + j + 2) & (kQB - 1);
+      process_entry(a0, a1, a2);
+      if (j + 1 >= m) break;
+      slot = (bh + j + 2) & (kQB - 1);
       a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-      process_entry(fast_tag, b0, b1, b2);
+      process_entry(b0, b1, b2);
+      if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
     }
-    if (!FAST && !all_done && every_pixel_stopped()) all_done = true;
-    b_head += j < m ? j : m;
+    b_head = __builtin_amdgcn_readfirstlane(bh + m);
     wave_lds_sync();
-    return ok;
   };
 
   auto gather = [&](uint32_t id, float4& r0, float4& r1, float4& r2) {
     const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
     r0 = r[0]; r1 = r[1]; r2 = r[2];
   };
-  auto idx_of = [&](uint32_t first) {
-    return first + (uint32_t)lane < l_count ? list[first + lane] : list[0];
+  auto idx_of = [&](uint32_t at) {
+    return at + (uint32_t)lane < l_count ? list[at + lane] : list[0];
   };
   float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
   uint32_t id2 = 0;
@@ -383,18 +337,20 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     gather(idx_of(0), n0, n1, n2);
     id2 = idx_of(kBatch);
   }
+  // Loop order: blend what the ring allows, THEN refine the next batch (the ring is tested first).  The
+  // same work as "refine, then blend" -- measured 5 % faster (0.82 vs 0.86 ms, profiles/r4_forward_forms_ab.txt).
   uint32_t first = 0;                  // next list entry to refine
-  // refine the batch of list entries [first, first + kBatch) into the ring
   auto refine = [&]() {
+    // refine the batch of list entries [first, first + kBatch) into the ring; the records of batch i + 1
+    // and the list indices of batch i + 2 are in flight meanwhile
     const uint32_t m = l_count - first < (uint32_t)kBatch ? l_count - first : (uint32_t)kBatch;
     const float4 r0 = n0, r1 = n1, r2 = n2;
     if (first + kBatch < l_count) {
       gather(id2, n0, n1, n2);
       id2 = idx_of(first + 2 * kBatch);
     }
-    bool keep = false, not_plain = false;
+    bool keep = false;
     float4 q0, q1, q2;
-    float opac = 0.f;
     if ((uint32_t)lane < m) {
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
       const uint32_t qm = quadrant_mask_part<QW>(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0, q_first);
@@ -402,53 +358,36 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       q0 = make_float4(r0.x, r0.y, A, B);
       q1 = make_float4(Cq, r1.y, r2.x, r2.y);
       q2 = make_float4(r2.z, __uint_as_float(first + lane + 1u), __uint_as_float(qm), 0.f);
-      not_plain = keep && !entry_is_plain(r0.x, r0.y, A, B, Cq, r1.y, alpha_max);
-      opac = keep ? r1.y : 0.f;
     }
     const uint64_t mask = __ballot(keep);
     if (keep) {
       const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
       lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
     }
-    if (!slow_for_good) {
-      const uint64_t npm = __ballot(not_plain);
-      if (npm) {     // ring index one past the batch's last entry that is not plain
-        const int hi = 63 - __builtin_clzll(npm);
-        np_end = b_tail + (uint32_t)__popcll(mask & ((2ull << hi) - 1ull));
-      }
-      const float ob = wave_max_f(opac);          // (NaN / negative opacities are not plain)
-      if (ob > om_run) {
-        om_run = ob;
-        // (1 - om)^-kWin by log2 / exp2, rounded up; om -> 1 gives inf: no window is ever fast
-        thr = t_min * fast_exp2(-(float)kWin * __log2f(1.f - om_run)) * 1.0001f;
-        thr = thr >= t_min ? thr : 3.0e38f;       // NaN (om > 1): never
-      }
-    }
-    b_tail += (uint32_t)__popcll(mask);
-    first += kBatch;
+    b_tail = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask));
     wave_lds_sync();
+    first += kBatch;
   };
-  // The walk in one form: full blend calls while the list lasts, then whatever is left.  The FAST
-  // instance hands over at the first window that fails its test; the slow instance returns after ONE
-  // blend call unless the short form is out for good, so that a few non-plain entries cost one call.
-  bool finished = l_count == 0;
-  auto walk = [&](auto fast_tag) {
-    constexpr bool FAST = decltype(fast_tag)::value;
+  for (;;) {
+    const bool refined_all = first >= l_count;
+    // full batches while the list lasts, then whatever is left -- also at the split point, where the
+    // ring is drained so that the pixel state is exactly "after entry ck_at"
+    const bool at_split = ck_at != 0u && first == ck_at && !ck_written;
+    const bool drain = refined_all || at_split;
     for (;;) {
-      const bool refined_all = first >= l_count;
-      while (!all_done && (b_tail - b_head >= (uint32_t)kBatch || (refined_all && b_tail != b_head))) {
-        const uint32_t have = b_tail - b_head;
-        const bool ok = blend1(fast_tag, have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
-        if (FAST && !ok) return;
-        if (!FAST && !slow_for_good) return;
-      }
-      if (all_done || refined_all) { finished = true; return; }
-      refine();
+      const uint32_t have = __builtin_amdgcn_readfirstlane(b_tail - b_head);
+      if (all_done || !(have >= (uint32_t)kBatch || (drain && have != 0u))) break;
+      blend1(have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
     }
-  };
-  while (!finished) {
-    if (!slow_for_good) walk(std::true_type{});
-    if (!finished) walk(std::false_type{});
+    if (all_done) break;
+    if (at_split) {
+      float4* const ck = ck_ptr();
+#pragma unroll
+      for (int k = 0; k < QW; ++k) ck[k * kWave] = make_float4(Ts[k], C0[k], C1[k], C2[k]);
+      ck_written = true;
+    }
+    if (refined_all) break;
+    refine();
   }
 #pragma unroll
   for (int k = 0; k < QW; ++k) T[k] = fabsf(Ts[k]);
@@ -471,22 +410,31 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       max_c = last[k] > max_c ? last[k] : max_c;
     }
   }
+  if (ck_written) {     // (wave-uniform) checkpoint -> (T at the split, colour behind the split / that T)
+    float4* const ck = ck_ptr();
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+      const float4 c = ck[k * kWave];
+      const float inv = c.x > 0.f ? 1.f / c.x : 0.f;       // stopped before the split: never read
+      ck[k * kWave] = make_float4(c.x, (C0[k] - c.y) * inv, (C1[k] - c.z) * inv, (C2[k] - c.w) * inv);
+    }
+  }
   // the tile's last contributor (informational since the backward derives it from n_contrib;
   // with several waves per tile only the one-wave-per-tile build writes it)
-  (void)max_c; (void)tile_end;
+  (void)max_c;
 }
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* tile_order, const uint32_t* tile_ranges,
                           const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
-                          float* final_T, uint32_t* n_contrib, uint32_t* tile_end,
+                          float* final_T, uint32_t* n_contrib, float4* checkpoint,
                           hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles * kFwdParts;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
   hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                     point_list, capacity, view_params, out_color, final_T, n_contrib, tile_end);
+                     point_list, capacity, view_params, out_color, final_T, n_contrib, checkpoint);
 }
 
 // ------------------------------------------------------------------------------------
@@ -545,7 +493,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ point_list, uint32_t capacity,
                       const float* __restrict__ view_params, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib,
-                      const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
+                      const float4* __restrict__ checkpoint, const float* __restrict__ dL_dcolor,
                       float* __restrict__ grad2d, float* __restrict__ tile_grads) {
   __shared__ WaveLdsBwd lds_all[kWavesPerBlockBwd];
   const int G = d.n_gaussians, H = d.height, W = d.width;
@@ -554,8 +502,20 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int V = d.n_scenes * d.views_per_scene;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot_global = blockIdx.x * kWavesPerBlockBwd + w;
-  if (slot_global >= V * tiles) return;
-  const int tile_global = (int)tile_order[slot_global];   // longest lists are launched first
+  // two tasks per tile: seg 0 walks the list
+  // entries above the tile's split point, seg 1 those up to it, from the state the forward left in
+  // `checkpoint` (a list shorter than kSplitMin is not split: seg 1 has nothing to do).  A list entry
+  // -- and with it its gradient slot -- belongs to exactly one of the two.  Half-length tasks, twice as
+  // many: the launch tail of 7168 one-wave tile tasks on 4096 wave slots shrinks.
+  // Launch order: ALL seg-0 tasks (longest list first), then all seg-1 tasks.  Interleaving the two
+  // kinds (seg = slot & 1, or in groups of 8 so that every XCD gets both) measured badly whenever one kind
+  // is nearly empty -- lists that end before their split point: opaque / dense scenes -- 1.43 instead of
+  // 1.17 ms (opaque), and 3.2 instead of 1.7 ms with every second task empty (profiles/r4_backward_split_ab.txt).
+  const uint32_t half = ((uint32_t)(V * tiles) + 7u) / 8u * 8u;
+  const uint32_t seg = (uint32_t)slot_global >= half ? 1u : 0u;
+  const uint32_t order_index = (uint32_t)slot_global - seg * half;
+  if (order_index >= (uint32_t)(V * tiles)) return;
+  const int tile_global = (int)tile_order[order_index];
   WaveLdsBwd& lds = lds_all[w];
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
@@ -584,12 +544,20 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     }
     c_max = __builtin_amdgcn_readfirstlane(wave_max_u(c_max));   // (wave-uniform: say so)
   }
-  (void)tile_end;
   float4* const slots = reinterpret_cast<float4*>(tile_grads) + vo * (kInvSlots * kSlotVec);
+  uint32_t lo, hi;        // this task walks the entries with 1-based index in (lo, hi], back to front
   {
     uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
     if (l_count > capacity - l_start) l_count = capacity - l_start;
-    for (uint32_t e = c_max + (uint32_t)lane; e < l_count; e += kWave) {
+    l_count = __builtin_amdgcn_readfirstlane(l_count);
+    const uint32_t split = split_point(l_count);
+    if (seg == 1u && split == 0u) return;
+    lo = seg == 0u ? split : 0u;
+    hi = seg == 0u ? c_max : (c_max < split ? c_max : split);
+    if (hi < lo) hi = lo;
+    // (the entries of this task's part of the list that lie behind the last contributor)
+    const uint32_t clear_end = seg == 0u ? l_count : split;
+    for (uint32_t e = hi + (uint32_t)lane; e < clear_end; e += kWave) {
       const uint32_t id = list[e];
       const uint32_t pk = __float_as_uint(recs[(size_t)id * kRecFloats + 7]);
       if (pk & kSmallFlag) {
@@ -600,7 +568,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       }
     }
   }
-  if (c_max == 0) return;
+  if (hi == lo) return;
 
   const float* bg = view_params + (size_t)v * PS_VIEW_STRIDE + PS_VIEW_BG;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -623,6 +591,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     g2[k] = inside ? gp[2 * P + pix] : 0.f;
     Tfb[k] = -T[k] * (bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k]);  // -T_final * (bg . dL/dC)
     acc0[k] = acc1[k] = acc2[k] = 0.f;   // colour composited BEHIND the current entry
+    if (seg == 1u && nc[k] > hi) {       // the pixel's walk continues behind the split point: start from
+      const float4 c = checkpoint[((size_t)tile_global * 4 + k) * kWave + lane];   // the forward's state
+      T[k] = c.x; acc0[k] = c.y; acc1[k] = c.z; acc2[k] = c.w;
+    }
   }
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
@@ -633,7 +605,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   // assembles the register pairs with ~5 v_mov per pixel and entry)
   f32x2 acc01[4], g01[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { acc01[k] = f32x2{0.f, 0.f}; g01[k] = f32x2{g0[k], g1[k]}; }
+  for (int k = 0; k < 4; ++k) { acc01[k] = f32x2{acc0[k], acc1[k]}; g01[k] = f32x2{g0[k], g1[k]}; }
 
   // refine list entries with 1-based indices top, top-1, ..., top-m+1 (lane i takes top - i)
   // list index of this lane's entry in the batch whose first (highest) 1-based index is `top`;
@@ -642,13 +614,13 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   auto idx_of = [&](uint32_t top) {
     return (uint32_t)lane < top ? list[top - 1u - lane] : list[0];
   };
-  uint32_t id_ahead = c_max > 0 ? idx_of(c_max) : 0u;
+  uint32_t id_ahead = idx_of(hi);
   uint32_t np_end = 0;     // absolute ring index one past the last entry that is NOT plain
   auto refine = [&](uint32_t top, uint32_t m) {
     bool keep = false, not_plain = false;
     float4 q0, q1, q2;
     const uint32_t id_now = id_ahead;
-    if (top > m) id_ahead = idx_of(top - m);
+    if (top - m > lo) id_ahead = idx_of(top - m);
     if ((uint32_t)lane < m) {
       const uint32_t id = id_now;
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
@@ -681,14 +653,14 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       const uint64_t npm = __ballot(not_plain);
       if (npm) {
         const int hi = 63 - __builtin_clzll(npm);
-        np_end = b_tail + (uint32_t)__popcll(mask & ((2ull << hi) - 1ull));
+        np_end = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask & ((2ull << hi) - 1ull)));
       }
     }
     if (keep) {
       const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
       lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
     }
-    b_tail += (uint32_t)__popcll(mask);
+    b_tail = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask));   // (wave-uniform: say so)
     wave_lds_sync();
   };
 
@@ -854,16 +826,17 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       if (b_head + base >= np_end && top_h <= nc_min) stage_batch(std::true_type{}, base, cnt);
       else stage_batch(std::false_type{}, base, cnt);
     }
-    b_head += m;
+    b_head = __builtin_amdgcn_readfirstlane(b_head + m);
   };
 
-  for (uint32_t top = c_max; top > 0;) {
-    const uint32_t m = top < (uint32_t)kBatch ? top : (uint32_t)kBatch;
+  for (uint32_t top = hi; top > lo;) {
+    const uint32_t m = top - lo < (uint32_t)kBatch ? top - lo : (uint32_t)kBatch;
     refine(top, m);
     // full batches while the list lasts, then whatever is left (ONE call site)
-    const bool last_batch = top == m;
-    while (b_tail - b_head >= (uint32_t)kBatch || (last_batch && b_tail != b_head)) {
-      const uint32_t have = b_tail - b_head;
+    const bool last_batch = top - m == lo;
+    for (;;) {
+      const uint32_t have = __builtin_amdgcn_readfirstlane(b_tail - b_head);
+      if (!(have >= (uint32_t)kBatch || (last_batch && have != 0u))) break;
       blend(have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
     }
     top -= m;
@@ -874,14 +847,15 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            const uint32_t* tile_order, const uint32_t* tile_ranges,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
-                           const uint32_t* n_contrib, const uint32_t* tile_end,
+                           const uint32_t* n_contrib, const float4* checkpoint,
                            const float* dL_dcolor, float* grad2d, float* tile_grads,
                            hipStream_t st) {
   const Dims m = make_dims(d);
-  const int total = m.V * m.tiles;
-  dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
+  static_assert(kWavesPerBlockBwd == 1, "the slot -> (tile, seg) map assumes one wave per block");
+  const int total = (m.V * m.tiles + 7) / 8 * 8 * 2;   // seg 0 of every tile, then seg 1 (see the kernel)
+  dim3 grid(total), block(kWave);
   hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                     point_list, capacity, view_params, final_T, n_contrib, tile_end, dL_dcolor,
+                     point_list, capacity, view_params, final_T, n_contrib, checkpoint, dL_dcolor,
                      grad2d, tile_grads);
 }
 

@@ -56,18 +56,51 @@ def test_geometry_bit_exact(gpu_device, b, v, grid, s, seed):
     x0, y0, _, _, masks = E.bilinear_corners(cpu(g.xy_sample), h, w)
     rx0, ry0, _, _, rmasks = E.bilinear_corners(ref.xy_sample, h, w)
     assert torch.equal(x0, rx0) and torch.equal(y0, ry0) and torch.equal(masks, rmasks)
-    # depth: well-conditioned samples to 1e-4 relative, everything after the [near, far] clip
+    # depth (a6): closed-form two-ray depth here, a 3x3 lstsq per sample in the reference.  The arbiter is
+    # the oracle's formulas evaluated in float64.  No sample is excluded:
+    #   * well-conditioned samples (|cos| < 0.999 between the two rays): 2e-3 relative worst case, 1e-5
+    #     median, against the float32 oracle as before AND against float64;
+    #   * the near-parallel rest (conditioning ~ 1 / (1 - cos^2)) is COUNTED and must land on the same
+    #     side of the [near, far] clamp as the float64 depth (unless that sits within 1e-3 of a bound),
+    #     with a relative-disparity error bounded by the conditioning.
     d, rd = cpu(g.depth), ref.depths
     ab = (ref.directions[:, :, None, :, None, :] * E.world_rays(
         ref.xy_sample, ctx.extrinsics[:, E.heterogeneous_index(v)][:, :, :, None, None],
         k_inv[:, E.heterogeneous_index(v)][:, :, :, None, None])[1]).sum(-1)
+    d64 = E.sample(feat.double(), ctx.extrinsics.double(), ctx.intrinsics.double(), ctx.near.double(),
+                   ctx.far.double(), s).depths
     good = m[..., None] & (ab.abs() < 0.999)
     rel = ((d - rd).abs() / rd.abs().clamp(min=1e-6))[good]
     assert rel.numel() == 0 or rel.max() < 2e-3, rel.max()
     assert rel.numel() == 0 or rel.median() < 1e-5
+    rel64 = ((d.double() - d64).abs() / d64.abs().clamp(min=1e-6))[good]
+    assert rel64.numel() == 0 or (rel64.max() < 2e-3 and rel64.median() < 1e-5), (rel64.max(), rel64.median())
     nr, fr = ctx.near[:, :, None, None, None], ctx.far[:, :, None, None, None]
     ref_rel = E.relative_disparity(rd.maximum(nr).minimum(fr), nr, fr)
     assert (cpu(g.rel_disparity) - ref_rel)[good].abs().max() < 2e-3
+    # the near-parallel samples
+    hard = m[..., None] & ~(ab.abs() < 0.999)
+    n_hard = int(hard.sum())
+    if n_hard:
+        side = lambda t: (t > fr.to(t.dtype)).long() - (t < nr.to(t.dtype)).long()
+        cond = (1 - ab.double() ** 2).clamp(min=1e-12)
+        tol = (2e-3 * (2e-3 / cond).clamp(min=1.0)).clamp(max=1.0)       # ~ float32 eps / (1 - cos^2)
+        # (a depth within its own conditioning error of a bound may fall on either side of it)
+        band = ((d64 / nr.double() - 1).abs() < tol) | ((d64 / fr.double() - 1).abs() < tol)
+        # the reference's own discontinuity: `parallel = dot > 1 - 1e-5` sends the depth to 1e10; a dot
+        # product within float32 rounding of that threshold may be flagged either way (by the reference too)
+        flag_band = (ab.double() - (1 - 1e-5)).abs() < 1e-6
+        n_flag = int((hard & flag_band).sum())
+        wrong_side = hard & (side(d) != side(d64)) & ~band & ~flag_band
+        assert int(wrong_side.sum()) == 0, (int(wrong_side.sum()), n_hard)
+        rel64_disp = E.relative_disparity(d64.maximum(nr.double()).minimum(fr.double()), nr.double(), fr.double())
+        err = (cpu(g.rel_disparity).double() - rel64_disp).abs()
+        chk = hard & ~flag_band
+        assert bool((err[chk] <= tol[chk]).all()), float((err[chk] / tol[chk]).max())
+        print(f"\n[depth b={b} v={v} {grid}] near-parallel samples (|cos| >= 0.999): {n_hard} of "
+              f"{int((m[..., None].expand_as(hard)).sum())} ({n_flag} within rounding of the reference's parallel "
+              f"threshold), all others on the float64 side of the [near, far] clamp; "
+              f"max rel-disparity error there {float(err[hard].max()):.2e}")
 
 
 def test_degenerate_cameras(gpu_device):
@@ -122,10 +155,31 @@ def test_fused_attention_vs_reference_golden(gpu_device, name):
         w_out=g["attn.fn.to_out.0.weight"].to(dev), b_out=g["attn.fn.to_out.0.bias"].to(dev),
         heads=heads, depth_w=g["depth_w"].to(dev), depth_b=g["depth_b"].to(dev), octaves=10,
         return_attn=True)
-    # noise floor: the depth -> PE branch amplifies fp32 round-off by up to 2 pi 2^9
-    # (SURVEY.md Appendix B step 12); measured reference fp32-vs-fp64 ~1e-3 on these inputs
-    assert (attn.cpu() - g["attn_weights"]).abs().max() < 5e-3
-    assert ((y + x).cpu() - g["attn_out"]).abs().max() < 5e-3
+    # Yardstick: the golden also holds the SAME reference modules evaluated in
+    # float64.  |ref32 - ref64| is the reference's own float32 noise on these inputs -- its per-sample
+    # 3x3 lstsq, amplified by the 2 pi 2^9 gain of the positional encoding
+    # -- and the product may not be further from the float64 truth than twice that, per tensor, in the
+    # worst element, the 99th percentile and the mean.
+    def held_to_reference_noise(what, hip, ref32, ref64, floor):
+        hip, ref32, ref64 = (np.asarray(t, np.float64) for t in (hip, ref32, ref64))
+        e_hip, e_ref = np.abs(hip - ref64).ravel(), np.abs(ref32 - ref64).ravel()
+        for stat, f in (("max", np.max), ("p99", lambda e: np.quantile(e, 0.99)), ("mean", np.mean)):
+            assert f(e_hip) <= 2.0 * f(e_ref) + floor, \
+                (name, what, stat, float(f(e_hip)), float(f(e_ref)))
+        return float(e_hip.max()), float(e_ref.max())
+
+    ov_mask = g["overlaps"].numpy()[..., None]
+    # a6 (depth): after the [near, far] clip, as relative disparity -- what the encoding consumes
+    rd = held_to_reference_noise("rel_disparity", geo.rel_disparity.cpu().numpy() * ov_mask,
+                                 g["rel_disparity"].numpy() * ov_mask,
+                                 g["rel_disparity64"].numpy() * ov_mask, 1e-7)
+    # a7 / a8: attention weights and the layer's output
+    aw = held_to_reference_noise("attn_weights", attn.cpu().numpy(), g["attn_weights"].numpy(),
+                                 g["attn_weights64"].numpy(), 1e-6)
+    ao = held_to_reference_noise("attn_out", (y + x).cpu().numpy(), g["attn_out"].numpy(),
+                                 g["attn_out64"].numpy(), 2e-6)
+    print(f"\n[{name}] |hip - ref64| vs |ref32 - ref64| (max): rel_disparity {rd[0]:.2e} / {rd[1]:.2e}, "
+          f"attention weights {aw[0]:.2e} / {aw[1]:.2e}, output {ao[0]:.2e} / {ao[1]:.2e}")
 
 
 @pytest.mark.parametrize("dims", [
@@ -209,6 +263,106 @@ def test_fused_attention_vs_oracle_and_autograd(gpu_device, dims):
     for k in g_ref:
         scale = g_ref[k].abs().max().item()
         assert (g_hip[k] - g_ref[k]).abs().max() < 1e-4 * max(scale, 1e-3), k
+
+
+def _lstsq_rel_disparity(ctx, grid, s, v, dtype):
+    """Relative disparity of every sample by the REFERENCE's route, restated: `intersect_rays`
+    (projection.py:176-230) -- parallel test at 1 - 1e-5, normal equations of the two rays, ONE
+    torch.linalg.lstsq per sample in the working precision, 1e10 for parallel pairs -- then
+    get_depth's norm (epipolar_lines.py:280-292), the [near, far] clip and depth_to_relative_disparity
+    (epipolar_transformer.py:100-118).  Returns (rel [b,v,ov,r,s], xy_sample, overlaps) in `dtype`."""
+    ext, intr = ctx.extrinsics.to(dtype), ctx.intrinsics.to(dtype)
+    near, far = ctx.near.to(dtype), ctx.far.to(dtype)
+    h, w = grid
+    b = ext.shape[0]
+    smp = E.sample(torch.zeros((b, v, 1, h, w), dtype=dtype), ext, intr, near, far, s, with_depth=False)
+    idx = E.heterogeneous_index(v)
+    k_inv = torch.linalg.inv(intr)
+    o2, d2 = E.world_rays(smp.xy_sample, ext[:, idx][:, :, :, None, None], k_inv[:, idx][:, :, :, None, None])
+    o1 = smp.origins[:, :, None, :, None, :].expand_as(o2)
+    d1 = smp.directions[:, :, None, :, None, :].expand_as(d2)
+    parallel = (d1 * d2).sum(-1) > 1 - 1e-5
+    eye = torch.eye(3, dtype=dtype)
+    n1 = d1[..., :, None] * d1[..., None, :] - eye
+    n2 = d2[..., :, None] * d2[..., None, :] - eye
+    rhs = (n1 @ o1[..., None]) + (n2 @ o2[..., None])
+    p = torch.linalg.lstsq(n1 + n2, rhs).solution[..., 0]
+    p = torch.where(parallel[..., None], torch.full_like(p, 1e10), p)
+    depth = (p - o1).norm(dim=-1)
+    nr, fr = near[:, :, None, None, None], far[:, :, None, None, None]
+    return E.relative_disparity(depth.maximum(nr).minimum(fr), nr, fr), smp.xy_sample, smp.segment.overlaps
+
+
+@pytest.mark.parametrize("dims", [(2, 3, 16, 6, 8, 4, 2, 8), (1, 2, 128, 9, 9, 32, 4, 32),
+                                  (1, 2, 128, 64, 64, 32, 4, 128)])     # the last: the paper shape
+def test_fused_attention_vs_lstsq_depth_route(gpu_device, dims):
+    """The product's closed-form depth meets the reference's lstsq (the strict test
+    above feeds the oracle the product's own rel_disparity).  Here the oracle side computes ITS OWN depths
+    by the reference's route -- one torch.linalg.lstsq per sample -- twice: in float32 (what the reference
+    does) and in float64 (the truth of the same formulas).  The fused layer's output may not be further
+    from the float64 result than twice the float32 lstsq route is (its noise is the reference's own:
+    lstsq round-off amplified 2 pi 2^9 times by the depth encoding)."""
+    from pixelsplat_amd.epipolar import fused_cross_attention, sample_geometry
+
+    torch.manual_seed(0)
+    b, v, c, h, w, s, heads, dh = dims
+    ctx = _cams(b, v, 5)
+    feat = torch.randn(b, v, c, h, w)
+    dev = gpu_device
+    inner = heads * dh
+    P = dict(w_q=torch.randn(inner, c) * 0.3, w_kv=torch.randn(2 * inner, c) * 0.3,
+             w_out=torch.randn(c, inner) * 0.3, b_out=torch.randn(c) * 0.1,
+             depth_w=torch.randn(c, 20) * 0.3, depth_b=torch.randn(c) * 0.1)
+    if v > 2:
+        P["view_emb"] = torch.randn(v - 1, c) * 0.3
+    x = torch.randn(b * v * h * w, 1, c)
+
+    def unfused(dtype):
+        rel, xy, overlaps = _lstsq_rel_disparity(ctx, (h, w), s, v, dtype)
+        f = feat.to(dtype)
+        W = {k: t.to(dtype) for k, t in P.items()}
+        sampled = torch.stack([torch.stack([torch.stack([
+            E.gather_features(f[bi, int(E.heterogeneous_index(v)[vi, oi])],
+                              xy[bi, vi, oi].reshape(-1, 2)).reshape(h * w, s, c)
+            for oi in range(v - 1)]) for vi in range(v)]) for bi in range(b)])
+        kv = sampled * overlaps[..., None, None] + E.positional_encoding(rel, 10) @ W["depth_w"].T + W["depth_b"]
+        if "view_emb" in W:
+            kv = kv + W["view_emb"][None, None, :, None, None, :]
+        z = kv.permute(0, 1, 3, 4, 2, 5).reshape(b * v * h * w, s * (v - 1), c)
+        q = x.to(dtype) @ W["w_q"].T
+        k_, v_ = (z @ W["w_kv"].T).chunk(2, dim=-1)
+        sp = lambda t: t.reshape(t.shape[0], -1, heads, dh).transpose(1, 2)
+        a = ((sp(q) @ sp(k_).transpose(-1, -2)) * dh ** -0.5).softmax(-1)
+        y = (a @ sp(v_)).transpose(1, 2).reshape(-1, 1, inner) @ W["w_out"].T + W["b_out"]
+        return y.double(), a.double(), rel.double(), overlaps
+
+    y32, a32, rel32, ov = unfused(torch.float32)
+    y64, a64, rel64, _ = unfused(torch.float64)
+    geo = sample_geometry(ctx.extrinsics.to(dev), ctx.intrinsics.to(dev), ctx.near.to(dev),
+                          ctx.far.to(dev), (h, w), s, w2c=torch.linalg.inv(ctx.extrinsics).to(dev),
+                          k_inv=torch.linalg.inv(ctx.intrinsics).to(dev))
+    y_hip, a_hip = fused_cross_attention(x.to(dev), feat.permute(0, 1, 3, 4, 2).contiguous().to(dev), geo,
+                                         heads=heads, octaves=10, return_attn=True,
+                                         **{k: t.to(dev) for k, t in P.items()})
+    y_hip, a_hip = y_hip.cpu().double(), a_hip.cpu().double().reshape(a64.shape)
+    m5 = ov[..., None].double()
+    stats = {}
+    for what, hip, r32, r64, floor in (
+            ("rel_disparity", geo.rel_disparity.cpu().double() * m5, rel32 * m5, rel64 * m5, 1e-7),
+            ("attention weights", a_hip, a32, a64, 1e-6),
+            ("output", y_hip, y32, y64, 2e-5 * max(1.0, float(y64.abs().max())))):
+        e_hip, e_ref = (hip - r64).abs().flatten(), (r32 - r64).abs().flatten()
+        if e_hip.numel() > 4_000_000:        # (torch.quantile's size limit; a fixed stride keeps it exact enough)
+            e_hip_q, e_ref_q = e_hip[::8], e_ref[::8]
+        else:
+            e_hip_q, e_ref_q = e_hip, e_ref
+        for stat, f, a_, b_ in (("max", torch.max, e_hip, e_ref),
+                                ("p99", lambda e: torch.quantile(e, 0.99), e_hip_q, e_ref_q),
+                                ("mean", torch.mean, e_hip, e_ref)):
+            assert float(f(a_)) <= 2.0 * float(f(b_)) + floor, (what, stat, float(f(a_)), float(f(b_)))
+        stats[what] = (float(e_hip.max()), float(e_ref.max()))
+    print(f"\n[lstsq route {dims}] max |hip - f64| / max |lstsq f32 - f64|: "
+          + ", ".join(f"{k} {a_:.2e} / {b_:.2e}" for k, (a_, b_) in stats.items()))
 
 
 @pytest.mark.parametrize("b,v", [(7, 2), (4, 3)])
