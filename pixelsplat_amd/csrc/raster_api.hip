@@ -129,7 +129,7 @@ struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
   float* final_T; uint32_t* n_contrib; float4* checkpoint; uint32_t* tile_ranges;
   uint32_t* num_rendered; uint32_t* tile_order; uint8_t* clamp_bits;
-  uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *bin_counts;
+  uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *pass_info, *bin_counts;
 };
 FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   const PsRasterStateLayout L = make_state_layout(d);
@@ -147,6 +147,7 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
   p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
   p.block_hist = (uint32_t*)(tb + T.block_hist); p.bin_counts = (uint32_t*)(tb + T.bin_counts);
+  p.pass_info = (uint32_t*)(tb + T.pass_info);
   return p;
 }
 int check_sizes(const PsRasterDesc& d, size_t state_bytes, size_t temp_bytes) {
@@ -181,7 +182,7 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   }
   {
     Scope sc(G_SORT, st);
-    launch_sort(*d, p.keys_a, p.keys_b, p.vals_a, p.vals_b, p.block_hist, p.sorted_idx, p.rects,
+    launch_sort(*d, p.keys_a, p.keys_b, p.vals_a, p.vals_b, p.block_hist, p.pass_info, p.sorted_idx, p.rects,
                 p.sorted_rect, p.n_vis, st);
   }
   {

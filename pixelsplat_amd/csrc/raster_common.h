@@ -57,7 +57,7 @@ __host__ __device__ inline Dims make_dims(const PsRasterDesc& d) {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct TempLayout {
-  size_t keys_a, keys_b, vals_a, vals_b, block_hist, bin_counts, grad2d, total;
+  size_t keys_a, keys_b, vals_a, vals_b, block_hist, pass_info, bin_counts, grad2d, total;
 };
 
 inline TempLayout make_temp_layout(const PsRasterDesc& d) {
@@ -67,7 +67,8 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
   t.keys_b = o; o = align_up(o + m.N * 4);
   t.vals_a = o; o = align_up(o + m.N * 4);
   t.vals_b = o; o = align_up(o + m.N * 4);
-  t.block_hist = o; o = align_up(o + (size_t)m.V * 256 * m.nblk * 4);
+  t.block_hist = o; o = align_up(o + (size_t)m.V * 512 * m.nblk * 4);      // 9-bit digits
+  t.pass_info = o; o = align_up(o + ((size_t)m.V + (size_t)m.V * m.nblk) * 4);  // pass count | block maxima
   t.bin_counts = o; o = align_up(o + (size_t)m.V * m.nbin * m.tiles * 4);
   t.grad2d = 0;  // backward reuses the buffer from offset 0
   t.total = o;
@@ -123,7 +124,7 @@ void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const 
                                bool sh_colors, hipStream_t st);
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
-                 uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
+                 uint32_t* vals_b, uint32_t* block_hist, uint32_t* pass_info, uint32_t* sorted_idx,
                  const uint2* rects, uint2* sorted_rect, uint32_t* n_vis, hipStream_t st);
 
 void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,

@@ -1,30 +1,53 @@
-// Per-view stable LSD radix sort of (depth bits -> Gaussian id), 4 passes x 8 bits, all
-// views in one launch per pass.  Culled Gaussians carry key 0xFFFFFFFF: the first pass drops
-// them (it is also the compaction: n_vis[v] = its histogram total), the other three passes
-// only touch the n_vis[v] visible entries (40 % of the Gaussians at the paper config).
+// Per-view stable LSD radix sort of (depth bits -> Gaussian id), all views in one launch per pass.
+// Digits are 9 bits of (key - kmin), kmin = the bit pattern of the near-cull depth (every visible key
+// lies above it): the depths of a view span < 2^27 bit patterns in every configuration seen (0.2 .. 600
+// in units of the near plane: 2^26.2), so THREE passes sort a view; a view whose keys span more gets a
+// fourth pass over the top 5 bits -- decided per view on the device (the first pass's histogram kernel
+// leaves each block's largest key, the scan kernel turns them into the view's pass count), no host
+// round trip: the fourth pass's kernels are always launched and return at once for 3-pass views.
+// Round 3 ran 4 passes x 8 bits whatever the keys: 0.33 -> 0.27 ms at BASELINE configs[1].
+// Culled Gaussians carry key 0xFFFFFFFF: the first pass drops them (it is also the compaction:
+// n_vis[v] = its histogram total), the later passes only touch the n_vis[v] visible entries (40 % of the
+// Gaussians at the paper config).
 // Stability + ids emitted in ascending order give exactly the order
 // of the reference's (tile | depth) stable sort restricted to any tile, so
 // the per-tile lists the tile kernels walk are bit-identical to the reference's bins.
 //
 // Pass = histogram (per 4096-key block) -> per-view scan -> stable scatter.  Ranking inside a
-// block is wave-synchronous: 8 ballots build the mask of lanes that share my digit
+// block is wave-synchronous: 9 ballots build the mask of lanes that share my digit
 // (wave64 "match"), rank = popcount below me, a per-wave LDS counter carries the running
 // digit offsets across the wave's 16 sequential 64-key rows.
 #include "raster_common.h"
 
+#include <cstring>
+
 namespace ps {
 
+constexpr int kDigitBits = 9;
+constexpr int kDigits = 1 << kDigitBits;          // 512
+constexpr uint32_t kDigitMask = kDigits - 1;
+constexpr int kMaxPasses = 4;                     // 9 + 9 + 9 + 5 bits
+static_assert(kDigits <= kSortThreads / 2, "one thread per digit in the histogram / scan kernels");
+
+// pass_info[v] = number of passes view v needs (3 or 4); written by the first pass's scan kernel
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t kmin, int shift) {
+  return ((key - kmin) >> shift) & kDigitMask;
+}
 
 template <bool FIRST>
 __global__ void __launch_bounds__(kSortThreads)
 sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist, int G,
-                 int nblk, int shift, const uint32_t* __restrict__ n_vis) {
-  __shared__ uint32_t h[256];
+                 int nblk, int shift, uint32_t kmin, int pass, const uint32_t* __restrict__ n_vis,
+                 uint32_t* __restrict__ pass_info /* [V] pass count | [V][nblk] block maxima */) {
+  __shared__ uint32_t h[kDigits];
+  __shared__ uint32_t s_max;
   const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  if (!FIRST && pass >= (int)pass_info[v]) return;      // (a 3-pass view has no fourth pass)
   const int limit = FIRST ? G : (int)n_vis[v];
   const int base = blk * kSortChunk;
+  if (FIRST && t == 0) s_max = 0u;
   if (base < limit) {
-    if (t < 256) h[t] = 0;
+    if (t < kDigits) h[t] = 0;
     __syncthreads();
     const uint32_t* k = keys + (size_t)v * G;
     // all loads first, branch free (clamped index): a load inside `if (p < limit)` is waited
@@ -38,12 +61,27 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
       const int p = base + i * kSortThreads + t;
-      if (p < limit && (!FIRST || key[i] != kCulledKey)) atomicAdd(&h[(key[i] >> shift) & 0xFFu], 1u);
+      if (p < limit && (!FIRST || key[i] != kCulledKey)) atomicAdd(&h[digit_of(key[i], kmin, shift)], 1u);
+    }
+    if (FIRST) {     // the block's largest visible key (wave maximum, one LDS atomic per wave)
+      uint32_t mx = 0;
+#pragma unroll
+      for (int i = 0; i < kSortItems; ++i) {
+        const int p = base + i * kSortThreads + t;
+        if (p < limit && key[i] != kCulledKey) mx = key[i] > mx ? key[i] : mx;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(mx, o); mx = u > mx ? u : mx; }
+      if ((t & 63) == 0 && mx) atomicMax(&s_max, mx);
     }
     __syncthreads();
   }
-  if (t < 256)
-    block_hist[((size_t)v * nblk + blk) * 256 + t] = base < limit ? h[t] : 0u;   // [v][blk][digit]
+  if (t < kDigits)
+    block_hist[((size_t)v * nblk + blk) * kDigits + t] = base < limit ? h[t] : 0u;   // [v][blk][digit]
+  if (FIRST) {
+    __syncthreads();
+    if (t == 0) pass_info[gridDim.y + (size_t)v * nblk + blk] = base < limit ? s_max : 0u;
+  }
 }
 
 // one block per view: exclusive scan of block_hist[v] in (digit-major, block-minor) order.
@@ -52,11 +90,13 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
 // running loop over a digit-major array was a chain of nblk dependent, uncoalesced loads).
 constexpr int kScanRegs = 128;   // block histograms a thread keeps in registers (G <= 524 288)
 
-__global__ void __launch_bounds__(256)
-sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restrict__ n_vis) {
-  __shared__ uint32_t tot[256];
+__global__ void __launch_bounds__(kDigits)
+sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restrict__ n_vis,
+                 uint32_t kmin, int pass, uint32_t* __restrict__ pass_info) {
+  __shared__ uint32_t tot[kDigits];
   const int v = blockIdx.x, dgt = threadIdx.x;
-  uint32_t* row = block_hist + (size_t)v * nblk * 256 + dgt;     // element b at row[b * 256]
+  if (n_vis == nullptr && pass >= (int)pass_info[v]) return;
+  uint32_t* row = block_hist + (size_t)v * nblk * kDigits + dgt;     // element b at row[b * kDigits]
   // One block per view does this, so it is pure latency.  Up to kScanRegs blocks: ONE batch of
   // loads (branch free, clamped), the running sums stay in registers across the digit scan, one
   // batch of stores -- 2 memory round trips instead of 12 (load 16 / store 16, twice over).
@@ -65,7 +105,7 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restri
   uint32_t sum = 0;
   if (fits) {
 #pragma unroll
-    for (int i = 0; i < kScanRegs; ++i) c[i] = row[(size_t)(i < nblk ? i : 0) * 256];
+    for (int i = 0; i < kScanRegs; ++i) c[i] = row[(size_t)(i < nblk ? i : 0) * kDigits];
 #pragma unroll
     for (int i = 0; i < kScanRegs; ++i) {
       const uint32_t x = i < nblk ? c[i] : 0u;
@@ -76,18 +116,18 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restri
     for (int b0 = 0; b0 < nblk; b0 += 16) {
       uint32_t t16[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) t16[i] = row[(size_t)min(b0 + i, nblk - 1) * 256];
+      for (int i = 0; i < 16; ++i) t16[i] = row[(size_t)min(b0 + i, nblk - 1) * kDigits];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        if (b0 + i < nblk) { row[(size_t)(b0 + i) * 256] = sum; sum += t16[i]; }
+        if (b0 + i < nblk) { row[(size_t)(b0 + i) * kDigits] = sum; sum += t16[i]; }
       }
     }
   }
   tot[dgt] = sum;
   __syncthreads();
-  // exclusive scan over 256 digit totals (Hillis-Steele in LDS)
+  // exclusive scan over the digit totals (Hillis-Steele in LDS)
   uint32_t x = sum;
-  for (int off = 1; off < 256; off <<= 1) {
+  for (int off = 1; off < kDigits; off <<= 1) {
     const uint32_t y = (dgt >= off) ? tot[dgt - off] : 0u;
     __syncthreads();
     x += y; tot[dgt] = x;
@@ -97,46 +137,78 @@ sort_scan_kernel(uint32_t* __restrict__ block_hist, int nblk, uint32_t* __restri
   if (fits) {
 #pragma unroll
     for (int i = 0; i < kScanRegs; ++i)
-      if (i < nblk) row[(size_t)i * 256] = c[i] + excl;
+      if (i < nblk) row[(size_t)i * kDigits] = c[i] + excl;
   } else {
     for (int b0 = 0; b0 < nblk; b0 += 16) {
       uint32_t t16[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) t16[i] = row[(size_t)min(b0 + i, nblk - 1) * 256];
+      for (int i = 0; i < 16; ++i) t16[i] = row[(size_t)min(b0 + i, nblk - 1) * kDigits];
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        if (b0 + i < nblk) row[(size_t)(b0 + i) * 256] = t16[i] + excl;
+        if (b0 + i < nblk) row[(size_t)(b0 + i) * kDigits] = t16[i] + excl;
     }
   }
   // first pass only: its histogram skipped the culled keys, so the grand total is the number
   // of visible Gaussians of the view -- n_vis without any atomics
-  if (n_vis != nullptr && dgt == 255) n_vis[v] = x;
+  if (n_vis != nullptr && dgt == kDigits - 1) n_vis[v] = x;
+  // first pass only: the view's pass count from the blocks' largest keys (threads stride the blocks,
+  // LDS maximum): 3 when every (key - kmin) fits 27 bits
+  if (n_vis != nullptr) {
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int b = dgt; b < nblk; b += kDigits) {
+      const uint32_t k = pass_info[gridDim.x + (size_t)v * nblk + b];
+      mx = k > mx ? k : mx;
+    }
+    tot[dgt] = mx;
+    __syncthreads();
+    for (int off = kDigits / 2; off > 0; off >>= 1) {
+      if (dgt < off) tot[dgt] = tot[dgt + off] > tot[dgt] ? tot[dgt + off] : tot[dgt];
+      __syncthreads();
+    }
+    if (dgt == 0) {
+      const uint32_t span = tot[0] > kmin ? tot[0] - kmin : 0u;
+      pass_info[v] = (span >> (3 * kDigitBits)) ? 4u : 3u;
+    }
+  }
 }
 
-// LAST: the final pass also writes sorted_rect[pos] = rects[id] (the tile rects in depth order
-// for the binning kernels): the id is in a register here, so the gather's loads fly under the
-// ranking instead of being a kernel of their own (57 us of dependent 8-byte gathers).
-template <bool IOTA_VALS, bool LAST = false>
+// The view's LAST pass (pass index pass_info[v] - 1: known on the device only) writes the ids to
+// `sorted_idx` instead of the ping-pong buffer and also sorted_rect[pos] = rects[id] (the tile rects in
+// depth order for the binning kernels): the id is in a register here, so the gather's loads fly under
+// the ranking instead of being a kernel of their own (57 us of dependent 8-byte gathers).  MAYBE_LAST =
+// this launch can be a view's last pass (pass index >= 2).
+template <bool IOTA_VALS, bool MAYBE_LAST = false>
 __global__ void __launch_bounds__(kSortThreads)
 sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                     const uint32_t* __restrict__ block_hist, int G, int nblk, int shift,
+                    uint32_t kmin, int pass, const uint32_t* __restrict__ pass_info,
                     const uint32_t* __restrict__ n_vis, const uint2* __restrict__ rects = nullptr,
-                    uint2* __restrict__ sorted_rect = nullptr) {
+                    uint2* __restrict__ sorted_rect = nullptr, uint32_t* __restrict__ sorted_idx = nullptr) {
   constexpr int NW = kSortThreads / kWave;
-  __shared__ uint32_t cnt[NW][256];   // per-wave running digit counts
-  __shared__ uint32_t base[NW][256];  // global start of (wave, digit)
+  // per-wave running digit counts during the ranking, then (in place) the global start of (wave, digit)
+  __shared__ uint32_t cnt[NW][kDigits];
   const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   const int w = t >> 6, lane = t & 63;
   const int limit = IOTA_VALS ? G : (int)n_vis[v];
   if (blk * kSortChunk >= limit) return;
-  for (int i = t; i < NW * 256; i += kSortThreads) (&cnt[0][0])[i] = 0;
+  bool last = false;
+  if (MAYBE_LAST) {
+    const int np = (int)pass_info[v];
+    if (pass >= np) return;                         // (a 3-pass view has no fourth pass)
+    last = pass == np - 1;
+  }
+  {   // (16-byte stores: 8192 words by 1024 threads)
+    uint4* z = reinterpret_cast<uint4*>(&cnt[0][0]);
+    for (int i = t; i < NW * kDigits / 4; i += kSortThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   __syncthreads();
 
   const size_t vo = (size_t)v * G;
   const int start = blk * kSortChunk + w * (kSortChunk / NW);
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
-  uint2 rc[LAST ? kSortItems : 1];
+  uint2 rc[MAYBE_LAST ? kSortItems : 1];
   const uint64_t lt = lanemask_lt();
   // Every global load of the block's items is issued before the ranking starts, branch free
   // (clamped index, masked afterwards): keys and values in one round trip, the rect gathers of
@@ -150,9 +222,11 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     key[i] = keys_in[vo + pc];
     val[i] = IOTA_VALS ? (uint32_t)pc : vals_in[vo + pc];
   }
-  // the block's digit offsets (used after the ranking by threads 0..255; every thread loads)
-  const uint32_t digit_base = block_hist[((size_t)v * nblk + blk) * 256 + (t & 255)];
-  if (LAST) {
+  // the block's digit offsets (used after the ranking by threads 0..kDigits-1; every thread loads)
+  const uint32_t digit_base = block_hist[((size_t)v * nblk + blk) * kDigits + (t & kDigitMask)];
+  if (MAYBE_LAST) {
+    // unconditional (a load under `if (last)` is not speculated: it would be issued -- and waited for --
+    // at the join, instead of flying under the ranking); wasted only in pass 2 of a 4-pass view
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) rc[i] = rects[vo + val[i]];
   }
@@ -161,10 +235,10 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     const int p = start + i * kWave + lane;
     bool valid = p < limit;
     if (IOTA_VALS) valid = valid && key[i] != kCulledKey;
-    const uint32_t dg = (key[i] >> shift) & 0xFFu;
+    const uint32_t dg = digit_of(key[i], kmin, shift);
     uint64_t mask = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < kDigitBits; ++b) {
       const bool bit = (dg >> b) & 1u;
       const uint64_t bal = __ballot(bit);
       mask &= bit ? bal : ~bal;
@@ -180,56 +254,61 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     wave_lds_sync();
   }
   __syncthreads();
-  if (t < 256) {
+  if (t < kDigits) {
     uint32_t b = digit_base;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { base[i][t] = b; b += cnt[i][t]; }
+    for (int i = 0; i < NW; ++i) { const uint32_t c = cnt[i][t]; cnt[i][t] = b; b += c; }
   }
   __syncthreads();
+  uint32_t* const vout = (MAYBE_LAST && last) ? sorted_idx : vals_out;
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     if (rank[i] != kCulledKey) {
-      const uint32_t dg = (key[i] >> shift) & 0xFFu;
-      const uint32_t pos = base[w][dg] + rank[i];
-      if (!LAST) keys_out[vo + pos] = key[i];   // nobody reads the keys after the last pass
-      vals_out[vo + pos] = val[i];
-      if (LAST) sorted_rect[vo + pos] = rc[i];
+      const uint32_t dg = digit_of(key[i], kmin, shift);
+      const uint32_t pos = cnt[w][dg] + rank[i];
+      if (!(MAYBE_LAST && last)) keys_out[vo + pos] = key[i];   // nobody reads the keys after the last pass
+      vout[vo + pos] = val[i];
+      if (MAYBE_LAST) { if (last) sorted_rect[vo + pos] = rc[i]; }
     }
   }
 }
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
-                 uint32_t* vals_b, uint32_t* block_hist, uint32_t* sorted_idx,
+                 uint32_t* vals_b, uint32_t* block_hist, uint32_t* pass_info, uint32_t* sorted_idx,
                  const uint2* rects, uint2* sorted_rect, uint32_t* n_vis, hipStream_t st) {
   const Dims m = make_dims(d);
   dim3 grid(m.nblk, m.V), block(kSortThreads);
+  // every visible key is the bit pattern of a depth above the near-cull distance
+  uint32_t kmin = 0;
+  if (d.near_cull > 0.f) { const float nc = d.near_cull; memcpy(&kmin, &nc, 4); }
   uint32_t* kin = keys_a; uint32_t* kout = keys_b;
   uint32_t* vin = nullptr; uint32_t* vout = vals_b;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass * 8;
+  for (int pass = 0; pass < kMaxPasses; ++pass) {
+    const int shift = pass * kDigitBits;
     if (pass == 0)
       hipLaunchKernelGGL(sort_hist_kernel<true>, grid, block, 0, st, kin, block_hist, m.G, m.nblk,
-                         shift, n_vis);
+                         shift, kmin, pass, n_vis, pass_info);
     else
       hipLaunchKernelGGL(sort_hist_kernel<false>, grid, block, 0, st, kin, block_hist, m.G, m.nblk,
-                         shift, n_vis);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(256), 0, st, block_hist, m.nblk,
-                       pass == 0 ? n_vis : (uint32_t*)nullptr);
+                         shift, kmin, pass, n_vis, pass_info);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(m.V), dim3(kDigits), 0, st, block_hist, m.nblk,
+                       pass == 0 ? n_vis : (uint32_t*)nullptr, kmin, pass, pass_info);
     if (pass == 0)
       hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, block, 0, st, kin, vin, kout,
-                         vout, block_hist, m.G, m.nblk, shift, n_vis, (const uint2*)nullptr,
-                         (uint2*)nullptr);
-    else if (pass < 3)
+                         vout, block_hist, m.G, m.nblk, shift, kmin, pass, pass_info, n_vis,
+                         (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr);
+    else if (pass == 1)
       hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, block, 0, st, kin, vin, kout,
-                         vout, block_hist, m.G, m.nblk, shift, n_vis, (const uint2*)nullptr,
-                         (uint2*)nullptr);
+                         vout, block_hist, m.G, m.nblk, shift, kmin, pass, pass_info, n_vis,
+                         (const uint2*)nullptr, (uint2*)nullptr, (uint32_t*)nullptr);
     else
       hipLaunchKernelGGL((sort_scatter_kernel<false, true>), grid, block, 0, st, kin, vin, kout,
-                         vout, block_hist, m.G, m.nblk, shift, n_vis, rects, sorted_rect);
-    // ping-pong: keys a<->b ; vals: (iota)->b->a->b->sorted_idx
+                         vout, block_hist, m.G, m.nblk, shift, kmin, pass, pass_info, n_vis, rects,
+                         sorted_rect, sorted_idx);
+    // ping-pong: keys a<->b ; vals: (iota)->b->a->b->a (a view's last pass writes sorted_idx instead)
     uint32_t* tk = kin; kin = kout; kout = tk;
     vin = vout;
-    vout = (pass == 0) ? vals_a : (pass == 1) ? vals_b : sorted_idx;
+    vout = (vout == vals_b) ? vals_a : vals_b;
   }
 }
 

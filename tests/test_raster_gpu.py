@@ -67,6 +67,34 @@ def test_single_view_small(gpu_device, seed, n, hw):
     _grad_close(g["means2D"], ref["means2D"], "means2D")
 
 
+def test_depth_span_over_27_bits_takes_the_fourth_sort_pass(gpu_device):
+    """The depth sort runs three 9-bit passes on (key - bits(near cull)) and a fourth only for a view whose
+    keys span 2^27 bit patterns or more (raster_sort.hip).  Here the depths run from 0.5 to 4e5 (span
+    0x09c3... > 2^27): the image -- i.e. the blend ORDER of every pixel -- and the gradients must still
+    be the oracle's; next to it the same scene squeezed into 2 .. 4 (three passes)."""
+    for far_scale in (1.0, 1e5):
+        sc = small_scene(600, (48, 64), seed=21, dtype=np.float32)
+        rng = np.random.default_rng(5)
+        z = sc["means"][:, 2].copy()
+        # a third of the Gaussians pushed far away along their own ray (same pixel, tiny footprint there:
+        # scale the covariance with the depth so that they still cover pixels)
+        far = rng.random(len(z)) < 0.33
+        f = np.where(far, far_scale * rng.uniform(0.25, 1.0, len(z)), 1.0).astype(np.float32)
+        sc["means"] = (sc["means"] * f[:, None]).astype(np.float32)
+        sc["cov6"] = (sc["cov6"] * (f * f)[:, None]).astype(np.float32)
+        st = R.forward(dtype=np.float32, **sc)
+        key_span = int(np.float32(sc["means"][:, 2].max()).view(np.uint32)) - int(np.float32(0.2).view(np.uint32))
+        assert (key_span >= 1 << 27) == (far_scale > 1.0)
+        dL = np.random.default_rng(6).normal(size=(3, 48, 64)).astype(np.float32)
+        ref = R.backward(st, dL)
+        img, radii, g = _single_view_hip(sc, gpu_device, dL)
+        assert np.array_equal(radii, st.radii)
+        assert int((st.radii > 0).sum()) > 300
+        assert np.abs(img - st.image).max() < IMG_TOL, far_scale
+        _grad_close(g["means3D"], ref["means3D"], "means3D")
+        _grad_close(g["opacity"], ref["opacity"], "opacity")
+
+
 def test_colors_precomp_path(gpu_device):
     sc = small_scene(300, (48, 64), seed=11, dtype=np.float32, sh_degree=0)
     sc["colors"] = np.random.default_rng(1).uniform(0, 1, (300, 3)).astype(np.float32)

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q -k "raster or decoder or scene or config or graph or bench" > gpurun_out/r4d_gpu_tests.log 2>&1; tail -4 gpurun_out/r4d_gpu_tests.log
-timeout 600 tools/ab_variants.sh r4d_fwd_walk_ab "--steps 20 --warmup 3 --launch eager" r3:r3tiles walk0:walk0 walk1
+mkdir -p gpurun_out
+timeout 240 bash tools/timeline.sh r4g -- > /dev/null 2>&1
+grep -n "sort_" gpurun_out/r4g_timeline.txt | tail -12
+timeout 300 python -m pytest tests -m gpu -q -x -k "raster_gpu or config1_256 or fourth" 2>&1 | tail -3
