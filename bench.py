@@ -809,6 +809,15 @@ def main():
                 "raster_algorithmic_bytes_per_step": (1120.0 * G + 40.0 * npix) * V + 160.0 * D_total,
                 "raster_hbm_frac": round(((1120.0 * G + 40.0 * npix) * V + 160.0 * D_total)
                                          / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # the same formula with what THIS design reads / writes once per SCENE counted once per
+                # scene (the 340 B/Gaussian inputs in the forward and again in the backward, the 340
+                # B/Gaussian of gradients) instead of once per view: the contract's figure above charges
+                # them per view ("the formula is not what those kernels do")
+                "raster_bytes_inputs_once_per_scene": 3 * 340.0 * G * b + (100.0 * G + 40.0 * npix) * V
+                                                      + 160.0 * D_total,
+                "raster_hbm_frac_inputs_once_per_scene": round(
+                    (3 * 340.0 * G * b + (100.0 * G + 40.0 * npix) * V + 160.0 * D_total)
+                    / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -10,7 +10,7 @@ pat=${1:-tiles_}; tags=${2:-"abl2 abl1"}
 cd /tmp && export TMPDIR=/tmp
 for v in $tags; do
   rm -rf /tmp/pmc_$v
-  PIXELSPLAT_HIP_LIB=$R/pixelsplat_amd/libps_$v.so timeout 25 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_$v -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probes --launch eager > /dev/null 2>&1
+  PIXELSPLAT_HIP_LIB=$R/pixelsplat_amd/libps_$v.so timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_$v -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probes --launch eager > /dev/null 2>&1
   python - "$v" "$pat" <<'P'
 import csv, glob, sys, collections
 v, pat = sys.argv[1], sys.argv[2]
