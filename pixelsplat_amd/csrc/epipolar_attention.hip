@@ -15,6 +15,8 @@
 // corner reads), the gathered tokens live in LDS between the score and the context pass.
 #include "raster_common.h"
 
+#include <cstdlib>
+
 // Timing experiments (tools/build_variant.sh <tag> -DPS_ABLATE_ATTN=N; results invalid): the two
 // attention kernels without 1: the context accumulation, 2: scores and context, 3: scores, context and
 // the gather / encoding staging (what is left is the ray prologue, the softmax and the epilogue).
