@@ -25,7 +25,8 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
   __shared__ uint2 s_rect[kBinChunk];
   __shared__ uint32_t s_idx[WRITE ? kBinChunk : 1];
   const Dims m = make_dims(d);
-  const int v = blockIdx.y, b = blockIdx.x;
+  int v, b;
+  view_minor_block(b, v);
   const uint32_t n = n_vis[v];
   const uint32_t base = (uint32_t)b * kBinChunk;
   if (base >= n) return;  // bins past the visible prefix are never read
@@ -90,7 +91,8 @@ bin_count_grid_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
                       const uint32_t* __restrict__ n_vis, uint32_t* __restrict__ counts) {
   extern __shared__ int grid[];   // [(gy + 1)][(gx + 1)]
   const Dims m = make_dims(d);
-  const int v = blockIdx.y, b = blockIdx.x;
+  int v, b;
+  view_minor_block(b, v);
   const uint32_t n = n_vis[v];
   const uint32_t base = (uint32_t)b * kBinChunk;
   if (base >= n) return;  // bins past the visible prefix are never read

@@ -41,7 +41,9 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
                  uint32_t* __restrict__ pass_info /* [V] pass count | [V][nblk] block maxima */) {
   __shared__ uint32_t h[kDigits];
   __shared__ uint32_t s_max;
-  const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
+  int v, blk;
+  view_minor_block(blk, v);
   if (!FIRST && pass >= (int)pass_info[v]) return;      // (a 3-pass view has no fourth pass)
   const int limit = FIRST ? G : (int)n_vis[v];
   const int base = blk * kSortChunk;
@@ -80,7 +82,7 @@ sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ block
     block_hist[((size_t)v * nblk + blk) * kDigits + t] = base < limit ? h[t] : 0u;   // [v][blk][digit]
   if (FIRST) {
     __syncthreads();
-    if (t == 0) pass_info[gridDim.y + (size_t)v * nblk + blk] = base < limit ? s_max : 0u;
+    if (t == 0) pass_info[gridDim.y + (size_t)v * nblk + blk] = base < limit ? s_max : 0u;   // (gridDim.y = V)
   }
 }
 
@@ -189,7 +191,9 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   constexpr int NW = kSortThreads / kWave;
   // per-wave running digit counts during the ranking, then (in place) the global start of (wave, digit)
   __shared__ uint32_t cnt[NW][kDigits];
-  const int v = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
+  int v, blk;
+  view_minor_block(blk, v);
   const int w = t >> 6, lane = t & 63;
   const int limit = IOTA_VALS ? G : (int)n_vis[v];
   if (blk * kSortChunk >= limit) return;
