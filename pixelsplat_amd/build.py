@@ -16,11 +16,11 @@ LIB = os.path.join(HERE, "libpixelsplat_hip.so")
 # (source, extra flags).  The preprocess TU carries the integer-valued arithmetic (radius,
 # tile rect, depth key): no FMA contraction there so the bins are bit-reproducible.
 SOURCES = [
-    ("raster_preprocess.hip", ["-ffp-contract=off"] + os.environ.get("PS_EXTRA_PRE", "").split()),
+    ("raster_preprocess.hip", ["-ffp-contract=off"]),
     ("epipolar_geometry.hip", ["-ffp-contract=off"]),
     ("raster_sort.hip", []),
     ("raster_tiles.hip", []),
-    ("raster_backward.hip", os.environ.get("PS_EXTRA_BWD", "").split()),
+    ("raster_backward.hip", []),
     ("raster_api.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),

@@ -17,13 +17,6 @@
 
 #include <cstdlib>
 
-// Timing experiments (tools/build_variant.sh <tag> -DPS_ABLATE_ATTN=N; results invalid): the two
-// attention kernels without 1: the context accumulation, 2: scores and context, 3: scores, context and
-// the gather / encoding staging (what is left is the ray prologue, the softmax and the epilogue).
-#ifndef PS_ABLATE_ATTN
-#define PS_ABLATE_ATTN 0
-#endif
-
 namespace ps {
 
 constexpr int kMaxHeads = 4;
@@ -586,15 +579,9 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
     float ev[kMaxHeads];
     load_view_term(k, lane, t0, erow, dm.hs_e, qt + ray * dm.ld_q, ev);
-#if PS_ABLATE_ATTN != 3
     stage_chunk<CK>(dm, k, lane, t0, fmap);
-#endif
     float sc[kMaxHeads];
-#if PS_ABLATE_ATTN >= 2
-    for (int hh = 0; hh < kMaxHeads; ++hh) sc[hh] = ev[hh];
-#else
     chunk_scores<CK>(dm, k, lane, t0, Q, ev, erow != nullptr, sc);
-#endif
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
     float mx[kMaxHeads];
@@ -619,9 +606,7 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     for (int hh = 0; hh < kMaxHeads; ++hh)
       l_run[hh] = uniform(fmaf(l_run[hh], corr[hh], lane_bcast(ps[hh], 63)));
     A.scale(corr);
-#if PS_ABLATE_ATTN == 0
     chunk_context<CK, WITH_O>(dm, k, lane, t0, sc, A);
-#endif
     wave_lds_sync();        // the chunk buffers are overwritten by the next iteration
   }
 
@@ -682,15 +667,9 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
     float ev[kMaxHeads];
     load_view_term(k, lane, t0, erow, dm.hs_a, dfbar + ray * dm.ld_f, ev);
-#if PS_ABLATE_ATTN != 3
     stage_chunk<CK>(dm, k, lane, t0, fmap);
-#endif
     float da[kMaxHeads];
-#if PS_ABLATE_ATTN >= 2
-    for (int hh = 0; hh < kMaxHeads; ++hh) da[hh] = ev[hh];
-#else
     chunk_scores<CK>(dm, k, lane, t0, Q, ev, erow != nullptr, da);
-#endif
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
 #pragma unroll
@@ -706,9 +685,7 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
       if (!on) da[hh] = 0.f;
       dot[hh] += da[hh];
     }
-#if PS_ABLATE_ATTN == 0
     chunk_context<CK, WITH_O>(dm, k, lane, t0, da, A);
-#endif
     wave_lds_sync();
   }
   // the forward outputs that close the expressions: every load issued before the first use

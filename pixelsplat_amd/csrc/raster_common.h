@@ -21,10 +21,7 @@ constexpr uint32_t kSmallFlag = 0x80000000u;
 // A tile list of at least kSplitMin entries is walked by the backward as TWO tasks: entries above the
 // split point (a multiple of the refine batch) and entries up to it; the forward leaves every pixel's
 // state at the split point in state.checkpoint (raster_tiles.hip).  0 = not split.
-#ifndef PS_SPLIT_MIN
-#define PS_SPLIT_MIN 256        // (A/B: -DPS_SPLIT_MIN=0x7fffffff never splits)
-#endif
-constexpr uint32_t kSplitMin = PS_SPLIT_MIN;
+constexpr uint32_t kSplitMin = 256;
 __host__ __device__ inline uint32_t split_point(uint32_t l_count) {
   return l_count >= kSplitMin ? ((l_count >> 1) & ~63u) : 0u;
 }

@@ -26,9 +26,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef PS_ABLATE
-#define PS_ABLATE 0   // 1..3: timing experiments that drop part of a tile kernel's work (results invalid)
-#endif
 // Quadrants per forward wave.  2 = two waves per tile (top / bottom half, 2 pixels per lane): fewer
 // quadrants per wave = more, smaller tasks (7168 one-wave tile tasks on 4096 wave slots leave a launch
 // tail that costs ~14 % at BASELINE configs[1]) and fewer registers (more waves per SIMD), paid for with
@@ -193,10 +190,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   * the refine's two dependent global latencies (list -> record gather) are off the wave's critical
 //     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
 //     is refined and blended.
-#ifndef PS_FWD_WAVES
-#define PS_FWD_WAVES 6      // waves per SIMD the forward's register allocation aims at (80 VGPRs; the 16 spilled ones are only live outside the walk)
-#endif
-constexpr int kFwdMinWaves = PS_FWD_WAVES;
+constexpr int kFwdMinWaves = 6;      // waves per SIMD the forward's register allocation aims at (80 VGPRs, no spill)
 __global__ void __launch_bounds__(kWavesPerBlock* kWave, kFwdMinWaves)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ tile_order,
@@ -266,11 +260,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   // one ring entry against the (up to QW) quadrants of this wave it can reach
   auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
     const uint32_t hidx = __float_as_uint(q2.y);
-#if PS_ABLATE == 3   // timing experiment (tools/build_variant.sh): refine + ring only, no blend math
-    const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
-#else
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-#endif
 #pragma unroll
     for (int k = 0; k < QW; ++k) {
       if (qm & (1u << k)) {   // wave-uniform: the entry cannot reach the other quadrants
@@ -676,11 +666,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       constexpr bool FAST = decltype(fast_tag)::value;
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
-#if PS_ABLATE == 2   // timing experiment: no per-pixel math (and so no reduction)
-      const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z)) & 0u;
-#else
       const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-#endif
       float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
       float s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
       bool any = false;
@@ -735,12 +721,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         }
         Mx = M1.x; My = M1.y; Mxx = M2.x; Mxy = M2.y; s_r = s_rg.x; s_g = s_rg.y;
       }
-#if PS_ABLATE == 1   // timing experiment: per-pixel math kept, the nine wave sums and their hand-over dropped
-      asm volatile("" :: "v"(Mx), "v"(My), "v"(Mxx), "v"(Mxy), "v"(Myy), "v"(s_op), "v"(s_r), "v"(s_g), "v"(s_b));
-      if (false) {
-#else
       if (__any(any)) {
-#endif
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
         float r1, r2;
         wave_sum9_partials(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);

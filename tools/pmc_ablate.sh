@@ -1,6 +1,7 @@
 #!/bin/bash
-# SQ counters of kernels built with part of their work compiled out (PS_ABLATE / PS_ABLATE_ATTN), on the
-# GPU box.  Build the variants first:  tools/build_variant.sh abl1 -DPS_ABLATE=1   (att1: -DPS_ABLATE_ATTN=1)
+# SQ counters of kernels of VARIANT libraries (tools/build_variant.sh <tag> -D...), on the GPU box -- e.g. the timing
+# ablations of rounds 2 / 3 (PS_ABLATE*: parts of a kernel's work compiled out; those macros left the source in round 4,
+# the numbers are in profiles/r2f_tiles_ablation.txt, r2f_attention_ablation.txt, r3_attention_counters.txt).
 # usage: tools/pmc_ablate.sh [kernel-name substring, default "tiles_"] [variant tags, default "abl2 abl1"]
 #        e.g. tools/pmc_ablate.sh epipolar_attn "att3 att2 att1"
 # Prints per kernel the counters per launch in millions (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are
