@@ -50,17 +50,25 @@ def _alg_bytes(bench: dict) -> dict:
 
 
 def table(tag: str) -> str:
-    stats = list(csv.DictReader(open(os.path.join(PROF, f"{tag}_kernel_stats.csv"))))
-    traffic = json.load(open(os.path.join(PROF, f"{tag}_pmc_traffic.json")))
-    sq = json.load(open(os.path.join(PROF, f"{tag}_pmc_sq.json")))
+    # the STEP-ONLY statistics when they exist (every launch of a kernel is then the benchmarked workload;
+    # the statistics of the whole command also average over the parity block's and the probes' launches)
+    stats_name = f"{tag}_step_kernel_stats.csv"
+    if not os.path.exists(os.path.join(PROF, stats_name)):
+        stats_name = f"{tag}_kernel_stats.csv"
+    stats = list(csv.DictReader(open(os.path.join(PROF, stats_name))))
+
+    def _load(name):     # counter summaries are optional (the scene runs take none)
+        path = os.path.join(PROF, name)
+        return json.load(open(path)) if os.path.exists(path) else {"kernels": {}}
+    traffic, sq = _load(f"{tag}_pmc_traffic.json"), _load(f"{tag}_pmc_sq.json")
     bench_path = os.path.join(PROF, f"{tag}_bench.json")
     bench = json.loads(open(bench_path).read().strip().splitlines()[-1]) if os.path.exists(bench_path) else {}
     alg = _alg_bytes(bench) if bench else {}
     tkeys = {_short(k): v for k, v in traffic["kernels"].items()}
     skeys = {_short(k): v for k, v in sq["kernels"].items()}
     out = [
-        f"# every ps:: kernel of the {tag} bench run: rocprofv3 average duration (profiles/{tag}_kernel_stats.csv, all",
-        f"# launches of the process incl. the side probes), memory-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE,",
+        f"# every ps:: kernel of the {tag} bench run: rocprofv3 average duration (profiles/{stats_name}),",
+        f"# memory-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE,",
         f"# profiles/{tag}_pmc_traffic.json), the rate that makes, the algorithmic bytes of SURVEY.md 8(d) where the formula",
         f"# names the kernel, VALU instructions per launch and VALU-busy time (profiles/{tag}_pmc_sq.json).",
         f"# build: {traffic.get('build')}",
@@ -94,7 +102,7 @@ def table(tag: str) -> str:
 
 
 if __name__ == "__main__":
-    for tag in sys.argv[1:] or ["r3_c2", "r3_c4", "r3_c5"]:
+    for tag in sys.argv[1:] or ["r4_c2", "r4_c4", "r4_c5"]:
         text = table(tag)
         with open(os.path.join(PROF, f"{tag}_kernel_table.txt"), "w") as f:
             f.write(text)

@@ -16,7 +16,7 @@ out=gpurun_out
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 short="$args --steps 10 --warmup 2 --no-cpu-baseline"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o p -- python bench.py $short > $out/${tag}_prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o p -- python bench.py $short > $out/${tag}_prof.log 2>&1
 f=$(ls $out/${tag}_prof/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" $out/${tag}_kernel_stats.csv; else
   db=$(ls $out/${tag}_prof/*.db 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_kernel_stats.py "$db" > $out/${tag}_kernel_stats.csv; fi
@@ -26,7 +26,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_pmc$i -o p -- python bench.py $pmc > $out/${tag}_pmc$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_pmc$i -o p -- python bench.py $pmc > $out/${tag}_pmc$i.log 2>&1
 done
 python tools/pmc_summary.py $out/${tag}_pmc1/*counter_collection.csv $out/${tag}_pmc2/*counter_collection.csv > $out/${tag}_pmc_traffic.json 2>> $out/${tag}_prof.log
 python tools/pmc_sq_summary.py $out/${tag}_pmc3/*counter_collection.csv $out/${tag}_pmc4/*counter_collection.csv > $out/${tag}_pmc_sq.json 2>> $out/${tag}_prof.log
