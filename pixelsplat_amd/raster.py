@@ -338,6 +338,9 @@ def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
         # (lay.tile_end is reserved: not written since the forward runs two waves per tile)
         tile_ranges=view(lay.tile_ranges, V * tiles * 8, torch.int32, (V, tiles, 2)),
         num_rendered=view(lay.num_rendered, 8, torch.int32, (2,)),
+        # per pixel (quadrant, lane) of a tile whose list the backward walks as two tasks: T after the
+        # first half and the colour composited behind it over that T
+        checkpoint=view(lay.checkpoint, V * tiles * 256 * 16, torch.float32, (V, tiles, 4, 64, 4)),
     )
 
 
