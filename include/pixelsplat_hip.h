@@ -102,9 +102,8 @@ typedef struct PsRasterStateLayout {
   size_t n_vis;       /* uint32[V]                                                     */
   size_t final_T;     /* float[V][P]                                                   */
   size_t n_contrib;   /* uint32[V][P]: 1-based index (within the tile's list) of the last contributor */
-  size_t tile_end;    /* uint32[V][T]: reserved (round 2: max n_contrib in the tile; since round 3 the
-                         backward derives it from n_contrib and the forward -- two waves per tile --
-                         no longer writes it) */
+  size_t tile_end;    /* uint32[V][T]: the tile's last contributor = max n_contrib over its pixels (the tile forward's
+                         waves max into it; the backward orders its tasks by it and starts its walks there) */
   size_t tile_ranges; /* uint32[V][T][2]: (start, count) of the tile's list in point_list     */
   size_t num_rendered;/* uint32[2]: D = sum of tile counts, overflow flag (D > capacity)      */
   size_t tile_order;  /* uint32[V*T]: (view,tile) ids, longest list first (launch order)      */

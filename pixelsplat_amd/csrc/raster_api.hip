@@ -127,7 +127,7 @@ int ps_raster_state_layout(const PsRasterDesc* d, PsRasterStateLayout* out) {
 namespace {
 struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
-  float* final_T; uint32_t* n_contrib; float4* checkpoint; uint32_t* tile_ranges;
+  float* final_T; uint32_t* n_contrib; float4* checkpoint; uint32_t* tile_end; uint32_t* tile_ranges;
   uint32_t* num_rendered; uint32_t* tile_order; uint8_t* clamp_bits;
   uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *pass_info, *bin_counts;
 };
@@ -140,6 +140,7 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.sorted_idx = (uint32_t*)(sb + L.sorted_idx); p.sorted_rect = (uint2*)(sb + L.sorted_rect);
   p.n_vis = (uint32_t*)(sb + L.n_vis); p.final_T = (float*)(sb + L.final_T);
   p.n_contrib = (uint32_t*)(sb + L.n_contrib); p.checkpoint = (float4*)(sb + L.checkpoint);
+  p.tile_end = (uint32_t*)(sb + L.tile_end);
   p.tile_ranges = (uint32_t*)(sb + L.tile_ranges);
   p.num_rendered = (uint32_t*)(sb + L.num_rendered);
   p.tile_order = (uint32_t*)(sb + L.tile_order);
@@ -188,7 +189,7 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   {
     Scope sc(G_BINS, st);
     launch_bin_count(*d, p.sorted_rect, p.n_vis, p.bin_counts, p.tile_ranges, p.num_rendered,
-                     p.tile_order, st);
+                     p.tile_order, p.tile_end, st);
   }
   return check_launch();
 }
@@ -235,7 +236,7 @@ int ps_raster_forward_tiles(const PsRasterDesc* d, const float* view_params, flo
   Scope sc(G_TILES_FWD, st);
   launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list,
                        clamp_capacity(list_capacity), view_params, out_color, p.final_T,
-                       p.n_contrib, p.checkpoint, st);
+                       p.n_contrib, p.checkpoint, p.tile_end, st);
   return check_launch();
 }
 
@@ -287,22 +288,25 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   const float* records = (const float*)(sb + L.records);
   const uint2* rects = (const uint2*)(sb + L.rects);
   const uint32_t* tile_ranges = (const uint32_t*)(sb + L.tile_ranges);
-  const uint32_t* tile_order = (const uint32_t*)(sb + L.tile_order);
+  const uint32_t* tile_end = (const uint32_t*)(sb + L.tile_end);
   const float* final_T = (const float*)(sb + L.final_T);
   const uint32_t* n_contrib = (const uint32_t*)(sb + L.n_contrib);
   const float4* checkpoint = (const float4*)(sb + L.checkpoint);
   float* grad2d = (float*)(tb + T.grad2d);
   float* tile_grads = (float*)(tb + T.tile_grads);
-  if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
+  uint32_t* task_order = (uint32_t*)(tb + T.task_order);
+  {
     Scope sc(G_MEMSET, st);
     // only the grad2d rows the tile backward adds into with atomics (pairs over > kInvSlots
     // tiles); the private slots are written exactly once each and need no clearing
-    launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
+    if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
+    // the tile backward's tasks, longest WALK first (the forward left every tile's last contributor)
+    launch_backward_task_order(*d, tile_ranges, tile_end, capacity, task_order, st);
   }
   {
     Scope sc(G_TILES_BWD, st);
-    launch_tiles_backward(*d, records, tile_order, tile_ranges, point_list, capacity, view_params,
-                          final_T, n_contrib, checkpoint, dL_dcolor, grad2d, tile_grads, st);
+    launch_tiles_backward(*d, records, task_order, tile_ranges, point_list, capacity, view_params,
+                          final_T, n_contrib, checkpoint, tile_end, dL_dcolor, grad2d, tile_grads, st);
   }
   {
     Scope sc(G_PRE_BWD, st);

@@ -157,7 +157,8 @@ bin_scan_blocks_kernel(PsRasterDesc d, const uint32_t* __restrict__ n_vis,
 __global__ void __launch_bounds__(1024)
 bin_scan_tiles_kernel(PsRasterDesc d, uint32_t* __restrict__ tile_ranges,
                       uint32_t* __restrict__ num_rendered /*[2]: D, overflow*/,
-                      uint32_t* __restrict__ tile_order) {
+                      uint32_t* __restrict__ tile_order,
+                      uint32_t* __restrict__ tile_end /* cleared: the tile forward's waves max into it */) {
   __shared__ uint32_t part[1024];
   __shared__ uint32_t hist[1024];
   __shared__ uint32_t s_max;
@@ -204,6 +205,7 @@ bin_scan_tiles_kernel(PsRasterDesc d, uint32_t* __restrict__ tile_ranges,
     num_rendered[0] = x;
     num_rendered[1] = 0u;
   }
+  for (int i = lo; i < hi; ++i) tile_end[i] = 0u;
   // Longest-list-first launch order for the tile kernels (one wave per tile, dispatched in
   // block order => LPT scheduling): counting sort of the tiles by list length, 1024 buckets.
   if (threadIdx.x == 0) s_max = 1u;
@@ -265,7 +267,7 @@ __global__ void bin_flag_kernel(uint32_t* __restrict__ num_rendered, uint32_t ca
 // count + scans: everything that does not need the point list (whose size, D, they produce)
 void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,
                       uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,
-                      uint32_t* tile_order, hipStream_t st) {
+                      uint32_t* tile_order, uint32_t* tile_end, hipStream_t st) {
   const Dims m = make_dims(d);
   dim3 grid(m.nbin, m.V);
   const int cells = (m.gx + 1) * (m.gy + 1);
@@ -279,7 +281,7 @@ void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uin
   hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3((m.V * m.tiles + 255) / 256), dim3(256), 0, st,
                      d, n_vis, counts, tile_ranges);
   hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, d, tile_ranges,
-                     num_rendered, tile_order);
+                     num_rendered, tile_order, tile_end);
 }
 
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,

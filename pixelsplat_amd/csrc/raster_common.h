@@ -78,7 +78,7 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
 // clears the rows in use itself, ps_raster_backward_prepare clears all of it); color_grads is the compact
 // per-(view, Gaussian) dL/dRGB the geometry backward hands to the SH backward (12 B rows
 // instead of 3 floats out of every 36-byte grad2d row and 1 out of every 48-byte record)
-struct BwdTempLayout { size_t grad2d, tile_grads, zeroed, color_grads, total; };
+struct BwdTempLayout { size_t grad2d, tile_grads, zeroed, color_grads, task_order, total; };
 inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_capacity) {
   const Dims m = make_dims(d);
   BwdTempLayout t; size_t o = 0;
@@ -89,6 +89,8 @@ inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_cap
   (void)list_capacity;
   t.tile_grads = o; o = align_up(o + m.N * kInvSlots * kSlotFloats * 4);
   t.color_grads = o; o = align_up(o + m.N * 3 * 4);
+  // launch order of the tile backward's 2 tasks per tile, longest walk first (raster_tiles.hip)
+  t.task_order = o; o = align_up(o + (size_t)m.V * m.tiles * 2 * 4);
   t.total = o;
   return t;
 }
@@ -126,7 +128,7 @@ void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint
 
 void launch_bin_count(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* n_vis,
                       uint32_t* counts, uint32_t* tile_ranges, uint32_t* num_rendered,
-                      uint32_t* tile_order, hipStream_t st);
+                      uint32_t* tile_order, uint32_t* tile_end, hipStream_t st);
 void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
                       const uint32_t* n_vis, uint32_t* counts, const uint32_t* tile_ranges,
                       uint32_t* num_rendered, uint32_t* point_list,
@@ -137,15 +139,18 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, float4* checkpoint,
-                          hipStream_t st);
+                          uint32_t* tile_end, hipStream_t st);
 
+void launch_backward_task_order(const PsRasterDesc& d, const uint32_t* tile_ranges,
+                                const uint32_t* tile_end, uint32_t capacity, uint32_t* task_order,
+                                hipStream_t st);
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
-                           const uint32_t* tile_order, const uint32_t* tile_ranges,
+                           const uint32_t* task_order, const uint32_t* tile_ranges,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const float4* checkpoint,
-                           const float* dL_dcolor, float* grad2d, float* tile_grads,
-                           hipStream_t st);
+                           const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
+                           float* tile_grads, hipStream_t st);
 
 void launch_clear_atomic_rows(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
                               float* grad2d, hipStream_t st);

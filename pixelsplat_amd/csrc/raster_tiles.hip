@@ -198,7 +198,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ point_list, uint32_t capacity,
                      const float* __restrict__ view_params, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                     float4* __restrict__ checkpoint) {
+                     float4* __restrict__ checkpoint, uint32_t* __restrict__ tile_end) {
   constexpr int QW = kFwdQW;          // quadrants (= pixels per lane) of this wave
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int G = d.n_gaussians, H = d.height, W = d.width;
@@ -411,7 +411,10 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   }
   // the tile's last contributor (informational since the backward derives it from n_contrib;
   // with several waves per tile only the one-wave-per-tile build writes it)
-  (void)max_c;
+  // the tile's last contributor (both half-tile waves max into it; cleared by the binning's scan kernel):
+  // the backward orders its tasks by it and starts its walks there
+  max_c = wave_max_u(max_c);
+  if (lane == 0 && max_c != 0u) atomicMax(&tile_end[tile_global], max_c);
 }
 
 void launch_tiles_forward(const PsRasterDesc& d, const float* records,
@@ -419,12 +422,12 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, float4* checkpoint,
-                          hipStream_t st) {
+                          uint32_t* tile_end, hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles * kFwdParts;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
   hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                     point_list, capacity, view_params, out_color, final_T, n_contrib, checkpoint);
+                     point_list, capacity, view_params, out_color, final_T, n_contrib, checkpoint, tile_end);
 }
 
 // ------------------------------------------------------------------------------------
@@ -478,12 +481,13 @@ __device__ __forceinline__ void wave_sum9_partials(float a, float b, float c, fl
 // slower (2.17 ms).
 __global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, 4)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
-                      const uint32_t* __restrict__ tile_order,
+                      const uint32_t* __restrict__ task_order,
                       const uint32_t* __restrict__ tile_ranges,
                       const uint32_t* __restrict__ point_list, uint32_t capacity,
                       const float* __restrict__ view_params, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib,
-                      const float4* __restrict__ checkpoint, const float* __restrict__ dL_dcolor,
+                      const float4* __restrict__ checkpoint,
+                      const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
                       float* __restrict__ grad2d, float* __restrict__ tile_grads) {
   __shared__ WaveLdsBwd lds_all[kWavesPerBlockBwd];
   const int G = d.n_gaussians, H = d.height, W = d.width;
@@ -497,15 +501,16 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   // `checkpoint` (a list shorter than kSplitMin is not split: seg 1 has nothing to do).  A list entry
   // -- and with it its gradient slot -- belongs to exactly one of the two.  Half-length tasks, twice as
   // many: the launch tail of 7168 one-wave tile tasks on 4096 wave slots shrinks.
-  // Launch order: ALL seg-0 tasks (longest list first), then all seg-1 tasks.  Interleaving the two
-  // kinds (seg = slot & 1, or in groups of 8 so that every XCD gets both) measured badly whenever one kind
-  // is nearly empty -- lists that end before their split point: opaque / dense scenes -- 1.43 instead of
-  // 1.17 ms (opaque), and 3.2 instead of 1.7 ms with every second task empty (profiles/r4_backward_split_ab.txt).
-  const uint32_t half = ((uint32_t)(V * tiles) + 7u) / 8u * 8u;
-  const uint32_t seg = (uint32_t)slot_global >= half ? 1u : 0u;
-  const uint32_t order_index = (uint32_t)slot_global - seg * half;
-  if (order_index >= (uint32_t)(V * tiles)) return;
-  const int tile_global = (int)tile_order[order_index];
+  // Launch order = task_order: the tasks sorted by the length of their WALK, longest first
+  // (backward_task_order_kernel) -- the walk starts at the tile's last contributor, which the forward
+  // left in tile_end, not at the end of the list: where pixels stop early the list length says little
+  // about a task's duration, and tasks with little or nothing to do must not sit between working ones
+  // (interleaved, nearly-empty one-wave workgroups halved this kernel's throughput:
+  // profiles/r4_backward_split_ab.txt); sorted, they trail the grid.
+  if (slot_global >= 2 * V * tiles) return;
+  const uint32_t task = task_order[slot_global];
+  const int tile_global = (int)(task >> 1);
+  const uint32_t seg = task & 1u;
   WaveLdsBwd& lds = lds_all[w];
   const int v = tile_global / tiles, t = tile_global % tiles;
   const uint32_t tx = t % gx, ty = t / gx;
@@ -517,23 +522,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   l_start = __builtin_amdgcn_readfirstlane(l_start);       // (wave-uniform: say so)
   const uint32_t* list = point_list + l_start;
 
-  // entries behind the tile's last contributor are never blended (1-based index c_max); the
-  // geometry backward still sums the private slot of every (Gaussian, tile) pair of a small
-  // Gaussian, so the slots of those entries are cleared here (nothing is memset)
-  // the tile's last contributor = max of its pixels' n_contrib (derived here: with several forward
-  // waves per tile no single wave knows it; 5 extra loads per lane, off the critical path)
-  uint32_t c_max = 0;
-  {
-    const size_t Pn = (size_t)H * W;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int px = tx * kTile + 8 * (k & 1) + (lane & 7);
-      const int py = ty * kTile + 8 * (k >> 1) + (lane >> 3);
-      const uint32_t n = (px < W && py < H) ? n_contrib[(size_t)v * Pn + (size_t)py * W + px] : 0u;
-      c_max = n > c_max ? n : c_max;
-    }
-    c_max = __builtin_amdgcn_readfirstlane(wave_max_u(c_max));   // (wave-uniform: say so)
-  }
+  // entries behind the tile's last contributor are never blended (1-based index c_max, left by the
+  // forward in tile_end); the geometry backward still sums the private slot of every (Gaussian, tile)
+  // pair of a small Gaussian, so the slots of those entries are cleared here (nothing is memset)
+  const uint32_t c_max = __builtin_amdgcn_readfirstlane(tile_end[tile_global]);
   float4* const slots = reinterpret_cast<float4*>(tile_grads) + vo * (kInvSlots * kSlotVec);
   uint32_t lo, hi;        // this task walks the entries with 1-based index in (lo, hi], back to front
   {
@@ -824,20 +816,99 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   }
 }
 
+// Launch order of the tile backward: its 2 x V x tiles tasks sorted by walk length, longest first
+// (counting sort into 1024 buckets, one block: pure latency, ~15 us).  Task id = tile << 1 | seg.
+__global__ void __launch_bounds__(1024)
+backward_task_order_kernel(int n_tiles, const uint32_t* __restrict__ tile_ranges,
+                           const uint32_t* __restrict__ tile_end, uint32_t capacity,
+                           uint32_t* __restrict__ task_order) {
+  __shared__ uint32_t hist[1024];
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t s_max;
+  const int n_tasks = 2 * n_tiles;
+  const int per = (n_tasks + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = lo + per < n_tasks ? lo + per : n_tasks;
+  auto walk = [&](int task) -> uint32_t {       // entries the task walks (tiles_backward_kernel: lo / hi)
+    const int tile = task >> 1;
+    uint32_t l_start = tile_ranges[2 * (size_t)tile], l_count = tile_ranges[2 * (size_t)tile + 1];
+    if (l_start > capacity) l_start = capacity;
+    if (l_count > capacity - l_start) l_count = capacity - l_start;
+    const uint32_t split = split_point(l_count), c = tile_end[tile];
+    if (task & 1) return c < split ? c : split;          // seg 1: (0, min(c_max, split)]
+    return c > split ? c - split : 0u;                    // seg 0: (split, c_max]
+  };
+  // a single block: pure latency.  The thread's (up to kPer) walk lengths are computed ONCE, every load
+  // issued before the first use, and kept in registers for all three uses (maximum, histogram, scatter)
+  constexpr int kPer = 16;
+  const bool fits = per <= kPer;                                  // uniform
+  uint32_t wl[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) wl[u] = walk(lo + u < n_tasks ? lo + u : n_tasks - 1);   // (unused when !fits)
+  if (threadIdx.x == 0) s_max = 1u;
+  hist[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t mx = 0;
+  if (fits) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) if (lo + u < hi) mx = wl[u] > mx ? wl[u] : mx;
+  } else {
+    for (int i = lo; i < hi; ++i) { const uint32_t c = walk(i); mx = c > mx ? c : mx; }
+  }
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const uint32_t maxc = s_max;
+  auto bucket = [&](uint32_t c) -> uint32_t {   // 0 = longest
+    return 1023u - (uint32_t)(((uint64_t)c * 1023ull) / maxc);
+  };
+  if (fits) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) if (lo + u < hi) atomicAdd(&hist[bucket(wl[u])], 1u);
+  } else {
+    for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(walk(i))], 1u);
+  }
+  __syncthreads();
+  const uint32_t hsum = hist[threadIdx.x];
+  part[threadIdx.x] = hsum;
+  __syncthreads();
+  uint32_t hx = hsum;
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t y = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    hx += y; part[threadIdx.x] = hx;
+    __syncthreads();
+  }
+  hist[threadIdx.x] = hx - hsum;   // exclusive start of the bucket
+  __syncthreads();
+  if (fits) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+      if (lo + u < hi) task_order[atomicAdd(&hist[bucket(wl[u])], 1u)] = (uint32_t)(lo + u);
+  } else {
+    for (int i = lo; i < hi; ++i) task_order[atomicAdd(&hist[bucket(walk(i))], 1u)] = (uint32_t)i;
+  }
+}
+
+void launch_backward_task_order(const PsRasterDesc& d, const uint32_t* tile_ranges,
+                                const uint32_t* tile_end, uint32_t capacity, uint32_t* task_order,
+                                hipStream_t st) {
+  const Dims m = make_dims(d);
+  hipLaunchKernelGGL(backward_task_order_kernel, dim3(1), dim3(1024), 0, st, m.V * m.tiles, tile_ranges,
+                     tile_end, capacity, task_order);
+}
+
 void launch_tiles_backward(const PsRasterDesc& d, const float* records,
-                           const uint32_t* tile_order, const uint32_t* tile_ranges,
+                           const uint32_t* task_order, const uint32_t* tile_ranges,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const float4* checkpoint,
-                           const float* dL_dcolor, float* grad2d, float* tile_grads,
-                           hipStream_t st) {
+                           const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
+                           float* tile_grads, hipStream_t st) {
   const Dims m = make_dims(d);
-  static_assert(kWavesPerBlockBwd == 1, "the slot -> (tile, seg) map assumes one wave per block");
-  const int total = (m.V * m.tiles + 7) / 8 * 8 * 2;   // seg 0 of every tile, then seg 1 (see the kernel)
-  dim3 grid(total), block(kWave);
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                     point_list, capacity, view_params, final_T, n_contrib, checkpoint, dL_dcolor,
-                     grad2d, tile_grads);
+  const int total = 2 * m.V * m.tiles;
+  dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
+  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, task_order, tile_ranges,
+                     point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
+                     dL_dcolor, grad2d, tile_grads);
 }
 
 }  // namespace ps

@@ -335,7 +335,7 @@ def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
         n_vis=view(lay.n_vis, V * 4, torch.int32, (V,)),
         final_T=view(lay.final_T, V * P * 4, torch.float32, (V, P)),
         n_contrib=view(lay.n_contrib, V * P * 4, torch.int32, (V, P)),
-        # (lay.tile_end is reserved: not written since the forward runs two waves per tile)
+        tile_end=view(lay.tile_end, V * tiles * 4, torch.int32, (V, tiles)),   # the tile's last contributor
         tile_ranges=view(lay.tile_ranges, V * tiles * 8, torch.int32, (V, tiles, 2)),
         num_rendered=view(lay.num_rendered, 8, torch.int32, (2,)),
         # per pixel (quadrant, lane) of a tile whose list the backward walks as two tasks: T after the
