@@ -265,6 +265,12 @@ typedef struct PsEpipolarDesc {
    * columns 0, c, c + P, a row is [q~_0 u_0 e_0 | q~_1 u_1 e_1 | ...]: the layout a batched
    * per-head GEMM produces without any permutation; hs_out likewise for fbar / pbar / abar. */
   int32_t hs_in, hs_out;
+  /* floats of padding behind each head's LAST block that the attention kernels fill with zeros
+   * themselves (tail_pad_out: behind abar, or behind pbar when e is NULL, in the forward;
+   * tail_pad_in: behind de, or du when de is NULL, in the backward), 0 ... 3: with a head stride
+   * rounded up to a multiple of 4 the caller's row-of-heads matrices then need no clearing pass
+   * before the GEMM that consumes them. */
+  int32_t tail_pad_in, tail_pad_out;
 } PsEpipolarDesc;
 int ps_epipolar_gather(const PsEpipolarDesc* desc, const float* fmap, const float* xy_sample,
                        const uint8_t* flags, float* features /*[b][v][v-1][h*w][s][c]*/,

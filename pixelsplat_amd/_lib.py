@@ -43,7 +43,7 @@ class PsRasterStateLayout(C.Structure):
 class PsEpipolarDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "v", "h", "w", "s", "c", "heads", "octaves",
                                          "ld_q", "ld_u", "ld_e", "ld_f", "ld_p", "ld_a",
-                                         "hs_in", "hs_out")]
+                                         "hs_in", "hs_out", "tail_pad_in", "tail_pad_out")]
 
 
 class PsDepthSamplerDesc(C.Structure):

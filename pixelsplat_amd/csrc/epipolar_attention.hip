@@ -621,6 +621,11 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
     }
     if (lane < k.P) pbar[ray * dm.ld_p + hh * dm.hs_p + lane] = A.p[hh] * inv;
     if (e != nullptr && lane < k.ovn) abar[ray * dm.ld_a + hh * dm.hs_a + lane] = A.o[hh] * inv;
+    if (lane < dm.pad_out) {      // the caller's padding behind the head's last block
+      float* tail = e != nullptr ? abar + ray * dm.ld_a + hh * dm.hs_a + k.ovn
+                                 : pbar + ray * dm.ld_p + hh * dm.hs_p + k.P;
+      tail[lane] = 0.f;
+    }
     for (int t = lane; t < k.T; t += kWave)
       attn[(rh + hh) * k.T + t] = __expf(k.scS[hh * k.T + t] - m_run[hh]) * inv;
   }
@@ -719,6 +724,11 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
       // of the single other view, i.e. one
       de[ray * dm.ld_e + hh * dm.hs_e + lane] =
           scale * (A.o[hh] - d * (abar != nullptr ? ab[hh] : 1.0f));
+    }
+    if (lane < dm.pad_in) {
+      float* tail = de != nullptr ? de + ray * dm.ld_e + hh * dm.hs_e + k.ovn
+                                  : du + ray * dm.ld_u + hh * dm.hs_u + k.P;
+      tail[lane] = 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {

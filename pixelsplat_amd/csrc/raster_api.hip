@@ -357,7 +357,8 @@ int ps_epipolar_geometry(int32_t b, int32_t v, int32_t h, int32_t w, int32_t s,
 namespace {
 bool epi_ok(const PsEpipolarDesc* d) {
   return d && d->b > 0 && d->v >= 2 && d->h > 0 && d->w > 0 && d->s > 0 && d->c > 0 &&
-         d->heads > 0 && d->octaves > 0;
+         d->heads > 0 && d->octaves > 0 && d->tail_pad_in >= 0 && d->tail_pad_in <= 3 &&
+         d->tail_pad_out >= 0 && d->tail_pad_out <= 3;
 }
 AttnDims to_dims(const PsEpipolarDesc* d) {
   const int P = 2 * d->octaves, ov = d->v - 1, H = d->heads;
@@ -366,7 +367,8 @@ AttnDims to_dims(const PsEpipolarDesc* d) {
                   ld(d->ld_q, H * d->c), ld(d->ld_u, H * P), ld(d->ld_e, H * ov),
                   ld(d->ld_f, H * d->c), ld(d->ld_p, H * P), ld(d->ld_a, H * ov),
                   ld(d->hs_in, d->c), ld(d->hs_in, P), ld(d->hs_in, ov),
-                  ld(d->hs_out, d->c), ld(d->hs_out, P), ld(d->hs_out, ov)};
+                  ld(d->hs_out, d->c), ld(d->hs_out, P), ld(d->hs_out, ov),
+                  d->tail_pad_in, d->tail_pad_out};
 }
 }  // namespace
 

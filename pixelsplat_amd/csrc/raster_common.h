@@ -179,6 +179,7 @@ void launch_epipolar_geometry(int b, int v, int h, int w, int s, const float* c2
 struct AttnDims {
   int b, v, h, w, s, c, heads, octaves, ld_q, ld_u, ld_e, ld_f, ld_p, ld_a;
   int hs_q, hs_u, hs_e, hs_f, hs_p, hs_a;   // head strides inside a row (default c, P, v-1)
+  int pad_in, pad_out;                      // zero-filled floats behind a head's last block (bwd / fwd)
 };
 int launch_epipolar_gather(const AttnDims& dm, const float* fmap, const float* xy,
                            const uint8_t* flags, float* out, hipStream_t st);

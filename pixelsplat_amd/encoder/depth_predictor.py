@@ -54,12 +54,18 @@ class _DepthSampler(torch.autograd.Function):
         ctx.desc = desc
         ctx.save_for_backward(projected, near, far, index)
         ctx.mark_non_differentiable(index)
+        ctx.set_materialize_grads(False)    # (no zero-filled "gradient" of the bucket index)
         return depth, opacity, index
 
     @staticmethod
     def backward(ctx, d_depth, d_opacity, _d_index):
         lib = _lib.load()
         projected, near, far, index = ctx.saved_tensors
+        if d_depth is None and d_opacity is None:
+            return (None,) * 10
+        shape = index.shape
+        d_depth = projected.new_zeros(shape) if d_depth is None else d_depth
+        d_opacity = projected.new_zeros(shape) if d_opacity is None else d_opacity
         d_projected = torch.empty_like(projected)
         _lib.check(lib.ps_depth_sampler_backward(
             C.byref(ctx.desc), _p(projected), _p(near), _p(far), _p(index),

@@ -25,11 +25,19 @@ class EpipolarGeometry:
     xy_max: Tensor       # [b, v, ov, r, 2]
     t_min: Tensor        # [b, v, ov, r]
     t_max: Tensor        # [b, v, ov, r]
-    overlaps: Tensor     # [b, v, ov, r] bool
     flags: Tensor        # [b, v, ov, r] uint8 (see include/pixelsplat_hip.h)
     xy_sample: Tensor    # [b, v, ov, r, s, 2]
     depth: Tensor        # [b, v, ov, r, s]
     rel_disparity: Tensor  # [b, v, ov, r, s]
+    _overlaps: Tensor | None = None
+
+    @property
+    def overlaps(self) -> Tensor:
+        """[b, v, ov, r] bool (`EpipolarSampling.valid`): bit 0 of `flags`, unpacked on first read --
+        the kernels of the hot path read `flags` itself."""
+        if self._overlaps is None:
+            self._overlaps = (self.flags & 1).bool()
+        return self._overlaps
 
 
 def sample_geometry(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
@@ -69,7 +77,7 @@ def sample_geometry(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: T
         _p(k), _p(k_inv), _p(nr), _p(fr), _p(origins), _p(directions), _p(seg), _p(flags),
         _p(xy_sample), _p(depth), _p(rel), _stream()), "ps_epipolar_geometry")
     return EpipolarGeometry(origins, directions, seg[..., 0:2], seg[..., 2:4], seg[..., 4],
-                            seg[..., 5], (flags & 1).bool(), flags, xy_sample, depth, rel)
+                            seg[..., 5], flags, xy_sample, depth, rel)
 
 
 # ---------------------------------------------------------------------------------------
@@ -428,6 +436,9 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         d = _desc(*dims)
         d.ld_q = d.ld_u = d.ld_e = d.ld_f = d.ld_p = d.ld_a = heads * lh
         d.hs_in = d.hs_out = lh
+        # the head stride is rounded up to a multiple of 4: the kernels zero the 0 ... 3 floats behind
+        # each head's last block themselves (no clearing pass over the [R, heads * lh] matrices)
+        d.tail_pad_in = d.tail_pad_out = lh - (c + 2 * octaves + ((v - 1) if has_e else 0))
         return d, lh
 
     @staticmethod
@@ -438,20 +449,19 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         d, lh = _FusedEpipolarAttention._desc(dims, has_e)
         fmap, qin = fmap.contiguous(), qin.contiguous()
         assert qin.shape == (R, heads * lh)
-        padded = lh != c + P + ((v - 1) if has_e else 0)
-        out = (torch.zeros if padded else torch.empty)((R, heads * lh), dtype=torch.float32,
-                                                       device=fmap.device)
+        out = torch.empty((R, heads * lh), dtype=torch.float32, device=fmap.device)
         attn = torch.empty((R, heads, T), dtype=torch.float32, device=fmap.device)
         col = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
         _lib.check(lib.ps_epipolar_attention_forward(
             C.byref(d), _p(fmap), _p(xy), _p(flags), _p(rd), col(qin, 0), col(qin, c),
             col(qin, c + P) if has_e else None, C.c_float(scale), col(out, 0), col(out, c),
             col(out, c + P), _p(attn), _stream()), "ps_epipolar_attention_forward")
-        ctx.dims, ctx.scale, ctx.has_e, ctx.padded = dims, scale, has_e, padded
+        ctx.dims, ctx.scale, ctx.has_e = dims, scale, has_e
         ctx.batch = batch
         ctx.batch_index = batch.register() if batch is not None else -1
         ctx.save_for_backward(fmap, xy, flags, rd, qin, attn, out)
         ctx.mark_non_differentiable(attn)
+        ctx.set_materialize_grads(False)    # (no zero-filled [R, heads, T] "gradient" of attn per backward)
         return out, attn
 
     @staticmethod
@@ -461,9 +471,9 @@ class _FusedEpipolarAttention(torch.autograd.Function):
         b, v, h, w, s, c, heads, octaves = ctx.dims
         R, T, P, ov = b * v * h * w, s * (v - 1), 2 * octaves, v - 1
         d, lh = _FusedEpipolarAttention._desc(ctx.dims, ctx.has_e)
-        dout = dout.contiguous()
+        dout = torch.zeros_like(out) if dout is None else dout.contiguous()
         f32 = dict(dtype=torch.float32, device=fmap.device)
-        dqin = (torch.zeros if ctx.padded else torch.empty)((R, heads * lh), **f32)
+        dqin = torch.empty((R, heads * lh), **f32)
         ds = torch.empty((R, heads, T), **f32)
         dfmap = boxes = None
         deferred = ctx.batch is not None and ctx.needs_input_grad[3]

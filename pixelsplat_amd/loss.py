@@ -52,10 +52,13 @@ class _Mse(torch.autograd.Function):
         sse, grad = _image_mse(pred, target, n_images, 2.0 * weight / n, ctx.needs_input_grad[0])
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(sse)
+        ctx.set_materialize_grads(False)
         return sse[0].sum() * (weight / n), sse
 
     @staticmethod
     def backward(ctx, d_loss, _d_sse):
+        if d_loss is None:
+            return None, None, None, None
         (grad,) = ctx.saved_tensors
         return grad * d_loss, None, None, None
 

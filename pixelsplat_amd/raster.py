@@ -255,10 +255,13 @@ class _Rasterize(torch.autograd.Function):
         ctx.save_for_backward(means, cov, opacity, sh, colors, view_params, r.radii, r.state,
                               r.point_list)
         ctx.mark_non_differentiable(r.radii)
+        ctx.set_materialize_grads(False)    # (no zero-filled [V, G] "gradient" of the radii per backward)
         return r.color, r.radii
 
     @staticmethod
     def backward(ctx, dL_dcolor, _dradii):
+        if dL_dcolor is None:
+            return (None,) * 8
         lib = _lib.load()
         cfg: RasterConfig = ctx.cfg
         means, cov, opacity, sh, colors, view_params, radii, state, plist = ctx.saved_tensors

@@ -526,6 +526,54 @@ def test_gemm_tn_splitk(gpu_device, m, n, k):
     assert (s4.cpu().double() - a.double().sum(0)).abs().max().item() < 2e-6 * k ** 0.5 * 4
 
 
+@pytest.mark.parametrize("v,c,octaves", [(3, 32, 10), (2, 32, 9), (4, 16, 10)])
+def test_attention_kernels_zero_the_head_padding(gpu_device, v, c, octaves):
+    """The head stride of the row-of-heads matrices is rounded up to a multiple of 4; the kernels
+    fill the 1 ... 3 floats behind each head's last block with zeros themselves (PsEpipolarDesc.
+    tail_pad_out / tail_pad_in) so that the caller passes uninitialised matrices to the consuming
+    GEMMs.  Both outputs are poisoned with NaN before the launch here."""
+    import ctypes as C
+    from pixelsplat_amd import _lib
+    from pixelsplat_amd.epipolar import _FusedEpipolarAttention as F, sample_geometry
+
+    torch.manual_seed(3)
+    lib = _lib.load()
+    b, h, w, s, heads = 2, 6, 5, 8, 4
+    dev = gpu_device
+    ctx = _cams(b, v, 7)
+    geo = sample_geometry(ctx.extrinsics.to(dev), ctx.intrinsics.to(dev), ctx.near.to(dev),
+                          ctx.far.to(dev), (h, w), s)
+    has_e = v > 2
+    dims = (b, v, h, w, s, c, heads, octaves)
+    d, lh = F._desc(dims, has_e)
+    used = c + 2 * octaves + ((v - 1) if has_e else 0)
+    assert d.tail_pad_out == lh - used and 1 <= lh - used <= 3
+    R, T, P = b * v * h * w, s * (v - 1), 2 * octaves
+    fmap = torch.randn(b * v, h, w, c, device=dev)
+    qin = torch.randn(R, heads * lh, device=dev)
+    out = torch.full((R, heads * lh), float("nan"), device=dev)
+    attn = torch.empty((R, heads, T), device=dev)
+    p = lambda t, off=0: C.c_void_p(t.data_ptr() + 4 * off)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ps_epipolar_attention_forward(
+        C.byref(d), p(fmap), p(geo.xy_sample), p(geo.flags), p(geo.rel_disparity), p(qin), p(qin, c),
+        p(qin, c + P) if has_e else None, C.c_float(0.25), p(out), p(out, c), p(out, c + P), p(attn), st),
+        "ps_epipolar_attention_forward")
+    dout = torch.randn(R, heads * lh, device=dev)
+    dqin = torch.full((R, heads * lh), float("nan"), device=dev)
+    ds = torch.empty((R, heads, T), device=dev)
+    _lib.check(lib.ps_epipolar_attention_backward(
+        C.byref(d), p(fmap), p(geo.xy_sample), p(geo.flags), p(geo.rel_disparity), p(qin), p(attn),
+        p(out), p(out, c), p(out, c + P) if has_e else None, p(dout), p(dout, c),
+        p(dout, c + P) if has_e else None, C.c_float(0.25), p(dqin), p(dqin, c),
+        p(dqin, c + P) if has_e else None, p(ds), None, None, st), "ps_epipolar_attention_backward")
+    for m in (out, dqin):
+        m3 = m.view(R, heads, lh)
+        assert torch.isfinite(m3).all()
+        assert (m3[:, :, used:] == 0).all()
+        assert m3[:, :, :used].abs().sum() > 0
+
+
 @pytest.mark.parametrize("v,c", [(2, 128), (3, 32)])
 def test_feature_grad_batch_matches_per_layer(gpu_device, v, c):
     """Two chained attention layers on one feature map: the deferred one-pass scatter of both
