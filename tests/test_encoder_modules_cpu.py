@@ -130,3 +130,33 @@ def test_sampling_features_are_gathered_on_first_access():
     assert none.features.shape == (2,)
     assert set(EpipolarSampling.FIELDS) == {"features", "valid", "xy_ray", "xy_sample", "xy_sample_near",
                                             "xy_sample_far", "origins", "directions"}
+
+
+def test_overlap_mask_is_unpacked_on_first_read():
+    """`EpipolarGeometry.overlaps` (= `EpipolarSampling.valid`, epipolar_sampler.py:66-75) is bit 0 of the
+    flag byte the geometry kernel writes; the kernels of the hot path read the flags themselves, so the bool
+    tensor is only made when somebody asks for it -- once."""
+    from pixelsplat_amd.epipolar import EpipolarGeometry
+
+    z = torch.zeros(1)
+    flags = torch.tensor([[0, 1, 2, 3, 7, 6]], dtype=torch.uint8)
+    geo = EpipolarGeometry(z, z, z, z, z, z, flags, z, z, z)
+    assert geo._overlaps is None
+    m = geo.overlaps
+    assert m.dtype == torch.bool and m.tolist() == [[False, True, False, True, True, False]]
+    assert geo.overlaps is m
+
+
+@pytest.mark.parametrize("c,octaves,v,has_e,lh,pad", [
+    (128, 10, 2, False, 148, 0),      # BASELINE configs[1]: 592 = 4 x 148, nothing to zero
+    (128, 10, 3, True, 152, 2),       # configs[3]: two floats behind the view term of each head
+    (32, 9, 2, False, 52, 2), (16, 10, 4, True, 40, 1), (64, 10, 2, True, 88, 3)])
+def test_head_stride_padding_is_handed_to_the_kernels(c, octaves, v, has_e, lh, pad):
+    """The attention kernels zero the padding behind each head's last block themselves
+    (PsEpipolarDesc.tail_pad_in / tail_pad_out); the descriptor the Python side builds must say how much."""
+    from pixelsplat_amd.epipolar import _FusedEpipolarAttention as F
+
+    d, width = F._desc((1, v, 4, 4, 8, c, 4, octaves), has_e)
+    assert width == lh == d.hs_in == d.hs_out and lh % 4 == 0
+    assert d.tail_pad_in == d.tail_pad_out == pad
+    assert d.ld_q == d.ld_f == 4 * lh
