@@ -265,12 +265,18 @@ template <int CK>
 __device__ __forceinline__ void stage_chunk(const AttnDims& dm, const RayCtx& k, int lane, int t0,
                                             const float* __restrict__ fmap) {
   constexpr int LPT = CK / 4, TPS = kWave / LPT;
-  const float inv_p = 1.0f / (float)k.P;
-  for (int idx = lane; idx < kChunk * k.P; idx += kWave) {
-    const int tl = (int)(((float)idx + 0.5f) * inv_p);
-    const int p = idx - tl * k.P;
-    const int t = min(t0 + tl, k.T - 1);
-    k.peS[tl * k.Ps + p] = pe_value(k.rdS[t], p);
+  {
+    // encodings: lane = 8 * token + j computes the dims j, j + 8, j + 16 of its token (the mapping of
+    // phase D): the token's disparity is read once and no index arithmetic is left per value (a loop
+    // over the chunk's kChunk * P values in lane order spent 12 of its 39 instructions per trip on
+    // idx -> (token, dim))
+    static_assert(kChunk * 8 == kWave, "lane = 8 * token + j");
+    const int tl = lane >> 3, j = lane & 7;
+    const float rdv = k.rdS[min(t0 + tl, k.T - 1)];
+    float* dst = k.peS + tl * k.Ps + j;
+#pragma unroll
+    for (int i = 0; i < kUPL; ++i)            // (8 * kUPL >= P: attn_dims_ok)
+      if (j + 8 * i < k.P) dst[8 * i] = pe_value(rdv, j + 8 * i);
   }
   const int lt = lane / LPT, ch = (lane % LPT) * 4;
   // TPS tokens per pass; the corner loads of NB passes are issued together (8 x 16 bytes per
@@ -577,11 +583,13 @@ epipolar_attn_forward_kernel(AttnDims dm, const float* __restrict__ fmap,
   const bool score_lane = (lane & 7) == 7;
 
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
-    float ev[kMaxHeads];
-    load_view_term(k, lane, t0, erow, dm.hs_e, qt + ray * dm.ld_q, ev);
+    // (WITH_O = "e is given", decided by the launcher: without a view term its loads, the token -> view
+    // index arithmetic in front of them and the selects in chunk_scores are not compiled at all)
+    float ev[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
+    if (WITH_O) load_view_term(k, lane, t0, erow, dm.hs_e, qt + ray * dm.ld_q, ev);
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float sc[kMaxHeads];
-    chunk_scores<CK>(dm, k, lane, t0, Q, ev, erow != nullptr, sc);
+    chunk_scores<CK>(dm, k, lane, t0, Q, ev, WITH_O && erow != nullptr, sc);
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
     float mx[kMaxHeads];
@@ -670,11 +678,12 @@ epipolar_attn_backward_kernel(AttnDims dm, const float* __restrict__ fmap,
   float dot[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
   const bool score_lane = (lane & 7) == 7;
   for (int t0 = 0; t0 < k.T; t0 += kChunk) {
-    float ev[kMaxHeads];
-    load_view_term(k, lane, t0, erow, dm.hs_a, dfbar + ray * dm.ld_f, ev);
+    // (WITH_O = "dabar or de is given", decided by the launcher)
+    float ev[kMaxHeads] = {0.f, 0.f, 0.f, 0.f};
+    if (WITH_O) load_view_term(k, lane, t0, erow, dm.hs_a, dfbar + ray * dm.ld_f, ev);
     stage_chunk<CK>(dm, k, lane, t0, fmap);
     float da[kMaxHeads];
-    chunk_scores<CK>(dm, k, lane, t0, Q, ev, erow != nullptr, da);
+    chunk_scores<CK>(dm, k, lane, t0, Q, ev, WITH_O && erow != nullptr, da);
     const int t = t0 + (lane >> 3);
     const bool live = score_lane && t < k.T;
 #pragma unroll
@@ -1580,7 +1589,7 @@ int launch_epipolar_attn_backward(const AttnDims& dm, const float* fmap, const f
                        du, de, ds);                                                             \
   } while (0)
 #define PS_GO1(L, O) do { if (two_rows) PS_GO2(L, O, 2); else PS_GO2(L, O, 1); } while (0)
-#define PS_GO(L) do { if (de != nullptr) PS_GO1(L, true); else PS_GO1(L, false); } while (0)
+#define PS_GO(L) do { if (de != nullptr || dabar != nullptr) PS_GO1(L, true); else PS_GO1(L, false); } while (0)
   PS_BY_LPT(PS_GO);
 #undef PS_GO
 #undef PS_GO1
