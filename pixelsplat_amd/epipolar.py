@@ -308,6 +308,7 @@ class FeatureGradBatch:
         self._done = None        # event: the side stream finished the flush
         self._keep = None        # tensors the side stream is using until then
         self._bins = None        # (token lists, scratch words) binned ahead of the flush
+        self._bins_inputs = None # (xy, flags, event) the side stream's binning reads / ends with
 
     def attach(self, fmap: Tensor) -> Tensor:
         if not (self.overlap and fmap.is_cuda and fmap.requires_grad and torch.is_grad_enabled()):
@@ -319,6 +320,23 @@ class FeatureGradBatch:
         if self._done is not None:
             torch.cuda.current_stream().wait_event(self._done)
         self._done = self._keep = None
+
+    def _release(self) -> None:
+        """The join node never ran (an exception between flush and join, a gradient nobody asked for):
+        what the side stream is reading must outlive its kernels -- wait for them on the host before the
+        references go (never reached inside a capture: a capture that ends with the side stream unjoined
+        fails on its own)."""
+        done, self._done = self._done, None
+        pending = [done] if (done is not None and self._keep is not None) else []
+        if getattr(self, "_bins_inputs", None) is not None:
+            pending.append(self._bins_inputs[2])
+        for ev in pending:
+            try:
+                if not torch.cuda.is_current_stream_capturing():
+                    ev.synchronize()
+            except Exception:
+                pass
+        self._keep = self._bins_inputs = None
 
     def register(self) -> int:
         if self.pending:
@@ -343,10 +361,16 @@ class FeatureGradBatch:
             with torch.cuda.stream(side):
                 _lib.check(lib.ps_epipolar_feature_bins(C.byref(desc), _p(xy), _p(flags), _p(boxes),
                                                         _stream()), "ps_epipolar_feature_bins")
+                binned = torch.cuda.Event()
+                binned.record(side)
             self._bins = boxes
+            # (the side stream reads the geometry of THIS layer's node, which the engine releases when
+            # this backward returns: held until the flush takes over, or until _release)
+            self._bins_inputs = (xy, flags, binned)
         self.pending.append((qin, attn, dout, ds))
 
     def __del__(self):
+        self._release()
         # the first-registered layer never ran its backward (its output was detached or unused)
         # while later layers parked their terms: those feature-map gradients were NOT applied
         if getattr(self, "pending", None):
@@ -364,6 +388,7 @@ class FeatureGradBatch:
             (max(flags.numel(), lib.ps_epipolar_ray_box_words(C.byref(desc))),),
             dtype=torch.int32, device=fmap.device)
         self._bins = None
+        bins_inputs, self._bins_inputs = self._bins_inputs, None     # (alive to the end of this call)
         # two-pass scheme: token gradients once (d(kv) of the reference: b v (v-1) h w s c floats of
         # caller-owned scratch, 0.94 GB at BASELINE configs[1], 1.6 GB at configs[3] -- it sits in
         # the backward-time peak, INTEGRATION.md "memory"), then the tile gather.  One scratch for
@@ -412,8 +437,15 @@ class FeatureGradBatch:
             if use_side:
                 self._done = torch.cuda.Event()
                 self._done.record(side)
-                # alive until the caller's stream has waited (join): the side stream is still reading
-                self._keep = (groups, dfmaps, boxes, scratch, total)
+                # alive until the caller's stream has waited (join): the side stream is still reading.
+                # EVERY operand of the launches above, not only what was allocated here: xy / flags /
+                # fmap are saved tensors of the calling autograd node, which the engine releases the
+                # moment this backward returns -- when nothing else holds the sampling geometry (bench.py's
+                # path_a) their blocks went back to the caller's stream while the side stream was still
+                # reading them, the next allocation of the backward overwrote the sample coordinates under
+                # the tile gather and its addresses went wild (GPU memory fault in replayed hipGraphs with a
+                # second process on the device, round 4; profiles/r5_fault_root_cause.txt)
+                self._keep = (groups, dfmaps, boxes, scratch, total, xy, flags, fmap, bins_inputs)
         return total
 
 
@@ -506,6 +538,15 @@ class _FoldWeights(torch.autograd.Function):
         tensors = [t if t is None else t.detach().to(torch.float32).contiguous()
                    for t in (w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb)]
         w_q, w_kv, w_out, b_out, depth_w, depth_b, view_emb = tensors
+        if w_q.is_cuda:
+            # EpipolarTransformer.fold_layers calls this on a side stream and autograd replays the backward
+            # there: an operand that was allocated on the caller's stream (the view embeddings) is
+            # released by the engine the moment that backward returns -- to the CALLER's stream, with the
+            # side stream's kernel still reading it.  record_stream defers the reuse (no-op for parameters)
+            cur = torch.cuda.current_stream()
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(cur)
         inner, d_in = w_q.shape
         c, d_out, p2 = w_kv.shape[1], w_out.shape[0], depth_w.shape[1]
         ov = 0 if view_emb is None else view_emb.shape[0]

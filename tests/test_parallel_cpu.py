@@ -294,7 +294,7 @@ def _forced_worker(rank, world, port, out):
 def test_forced_one_rank_communicator_runs_the_whole_reducer():
     """PIXELSPLAT_FORCE_COMM=1: a single rank builds a real process group, the hooks launch real
     collectives and the values do not change -- the mode the RCCL leg is run in on a one-GPU box
-    (tests/test_rccl_one_rank_gpu.py)."""
+    (tests/test_zz_rccl_one_rank_gpu.py)."""
     with mp.Manager() as m:
         out = m.dict()
         mp.spawn(_forced_worker, args=(1, 0, out), nprocs=1, join=True)

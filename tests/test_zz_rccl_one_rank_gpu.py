@@ -4,7 +4,7 @@ is what N ranks run: `init_process_group("nccl", device_id=...)`, the buckets' a
 on RCCL's own stream ordered against the compute stream, `finish()`'s waits, the exposed-wait timing,
 hipGraph capture and replay beside a live communicator (watchdog thread, `thread_local` capture mode),
 and the communicator block of the bench line.  The two-rank schedule itself is covered on gloo
-(tests/test_bench_ranks_gpu.py, tests/test_parallel_cpu.py); only xGMI traffic between devices is left
+(tests/test_zz_bench_ranks_gpu.py, tests/test_parallel_cpu.py); only xGMI traffic between devices is left
 to the driver's 8-GPU node."""
 import json
 import os
