@@ -66,6 +66,11 @@ def parse():
                         "if it fails the run falls back to eager launches and reports it); eager: "
                         "launch by launch.  `paths.eager_ms_per_step` carries the eager time of the "
                         "same step at every N either way")
+    p.add_argument("--connected", action="store_true",
+                   help="after the timed region also time ONE CONNECTED training step -- features -> "
+                        "EpipolarTransformer.forward (full module) -> EncoderEpipolarHead -> DecoderSplattingCUDA -> "
+                        "LossMse -> backward (pixelsplat_amd/training_step.py; model_wrapper.py:108-152) -- "
+                        "eager, reported as paths.connected_ms_per_step; not part of `value`")
     p.add_argument("--cpu-views", type=int, default=10 ** 6,
                    help="views in the CPU-baseline sample / parity block (default: every view of the step)")
     return p.parse_args()
@@ -308,6 +313,7 @@ def main():
     # fd 1 is pointed at stderr for the run and the line goes to a private duplicate of the real one
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
+    _STATE["json_out"] = json_out
     os.dup2(2, 1)
     rank, world, local = P.init_from_env()
     if world != args.gpus and rank == 0:
@@ -679,7 +685,7 @@ def main():
         # the rasterizer's > 4-tile Gaussians sum through float atomics (<= 2e-6 of max measured)
         bars = {"d_means": 2e-5, "d_cov": 2e-5, "d_sh": 2e-5, "d_opacity": 2e-5, "d_features": 1e-6,
                 "d_parameters_reduced": 1e-6, "tokens_out": 0.0, "image_vs_this_eager_step": 0.0,
-                "image_vs_oracle_checked_launch": 1e-6}
+                "image_vs_oracle_checked_launch": 1e-5}
         ok = all(errs[k] <= bars[k] for k in bars)
         graphs.update(saved_graphs)
         for t, g_ in saved_grads:
@@ -750,6 +756,54 @@ def main():
     for i in range(ng):   # the groups only these two probes launch
         if launches[i] == 0 and side_n[i]:
             tot_ms[i], launches[i] = side_ms[i], side_n[i]
+    connected = None
+    if args.connected:
+        # the halves composed: the SAME module classes, paper encoder config, random-init weights, the
+        # synthetic cameras of the step; the convolutions / image self-attention around the epipolar layers
+        # are PyTorch's (MIOpen / hipBLASLt), out of the hot path's scope but inside this number
+        from pixelsplat_amd.training_step import ConnectedStep
+        torch.manual_seed(0)
+        cs = ConnectedStep(et.cfg, d_feat, vc, head.cfg).to(dev)
+        cs_feat = torch.randn(b, vc, d_feat, *hw, device=dev).requires_grad_(True)
+        cs_ctx = dict(extrinsics=c_ext, intrinsics=c_intr, near=c_near, far=c_far)
+        cs_tgt = dict(extrinsics=tgt.extrinsics.to(dev), intrinsics=tgt.intrinsics.to(dev),
+                      near=tgt.near.to(dev), far=tgt.far.to(dev), image=tgt_img.reshape(b, v, 3, *hw))
+
+        def step_connected():
+            cs_feat.grad = None
+            for p_ in cs.parameters():
+                p_.grad = None
+            cs(cs_feat, cs_ctx, cs_tgt, global_step=0).loss.backward()
+
+        try:
+            step_connected()
+            torch.cuda.synchronize()
+            n_c = max(1, min(args.steps, 5))
+            lib_ms0 = (C.c_double * ng)()
+            lib_n0 = (C.c_int64 * ng)()
+            ms_c = timed(step_connected, n_c)
+            lib.ps_profile_enable(1)
+            for _ in range(n_c):
+                step_connected()
+            torch.cuda.synchronize()
+            lib.ps_profile_enable(0)
+            _lib.check(lib.ps_profile_collect(lib_ms0, lib_n0), "ps_profile_collect")
+            connected = {
+                "ms_per_step": round(ms_c, 3), "steps": n_c, "launch": "eager",
+                "library_kernels_ms_per_step": round(sum(lib_ms0[i] for i in range(ng)) / n_c, 3),
+                "views_per_s": round(V / ms_c * 1e3, 1),
+                "parameters_with_gradient": sum(1 for p_ in cs.parameters() if p_.grad is not None),
+                "parameters": sum(1 for _ in cs.parameters()),
+                "features_grad_finite": bool(torch.isfinite(cs_feat.grad).all()),
+                "what": "features [b,v,128,H,W] -> EpipolarTransformer.forward (full module incl. PyTorch's "
+                        "downscale / upscale / 7x7 refinement convolutions and image self-attention) -> "
+                        "EncoderEpipolarHead -> DecoderSplattingCUDA -> LossMse -> backward; random-init weights; "
+                        "library_kernels_ms = HIP-event time inside this library's launches, the rest is PyTorch's"}
+        except RuntimeError as err:
+            print(f"[bench] connected step skipped: {err}", file=sys.stderr)
+            connected = {"error": str(err)[:300]}
+        del cs, cs_feat
+        torch.cuda.empty_cache()
 
     comm_info = P.comm_info(world, dev)       # (a collective: every rank takes part)
     if rank == 0:
@@ -778,7 +832,46 @@ def main():
             "epipolar_attention_backward": fm + RA * (12.0 * TA + 4.0 * heads * (2 * d_feat + 2 * PA + 2 * TA)),
             "epipolar_feature_grad": fm + RA * (8.0 * TA + 4.0 * heads * (2 * d_feat + 2 * TA)),
         })
-        dom = max(alg, key=lambda k: groups[k][0])
+        # (A) against the fp32 vector peak: FOLDED useful flops = what the fused
+        # kernels have to compute per launch (score + context: 2 x (c + P) MACs per (ray, token, head);
+        # bilinear interpolation 4 corners x c MACs per token; token gradient 2 c MACs per (token, layer,
+        # head) + the 4-corner scatter) and the REFERENCE-EQUIVALENT flops of the same stage (to_kv on
+        # every token + QK^T + AV) -- the second is a folding artefact, not a utilisation
+        VEC_PEAK = 157.3      # TFLOP/s fp32 vector (packed FMA), MI355X_MICROARCH.md
+        n_layers_a = len(et.transformer.layers)
+        tok = float(RA) * TA
+        fold_attn = tok * heads * 2 * (d_feat + PA) * 2 + tok * 4 * d_feat * 2
+        ref_attn = 2.0 * tok * d_feat * 2 * heads * 128 + 2 * 2.0 * tok * heads * 128
+        flops_a = {
+            "epipolar_attention_forward": (fold_attn, ref_attn),
+            "epipolar_attention_backward": (fold_attn, 2 * ref_attn),
+            # one launch group per step, both layers at once
+            "epipolar_feature_grad": (tok * n_layers_a * heads * 2 * d_feat * 2 + tok * 4 * d_feat * 2, 0.0),
+        }
+        # the two-pass feature gradient writes and re-reads the token-gradient tensor: its floor
+        alg["epipolar_feature_grad"] = fm + 2 * 4.0 * tok * d_feat
+        roofline_a = {}
+        for k_, (ff, rf) in flops_a.items():
+            if k_ in groups and groups[k_][0] > 0:
+                # the feature-gradient group is timed per launch of its kernels: per step = ms x launches
+                ms_ = groups[k_][0] * (groups[k_][1] / args.steps if k_ == "epipolar_feature_grad" else 1.0)
+                roofline_a[k_] = {
+                    "ms": round(ms_, 4), "folded_gflop": round(ff / 1e9, 2),
+                    "folded_tflops": round(ff / (ms_ * 1e-3) / 1e12, 2),
+                    "frac_of_fp32_vector_peak": round(ff / (ms_ * 1e-3) / 1e12 / VEC_PEAK, 4),
+                    "reference_equivalent_gflop": round(rf / 1e9, 1) if rf else None,
+                    "reference_equivalent_tflops": round(rf / (ms_ * 1e-3) / 1e12, 1) if rf else None,
+                    "algorithmic_bytes": alg[k_],
+                    "algorithmic_frac_of_hbm_peak": round(alg[k_] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "valu_issue_frac": (round(pmc_valu_busy_ms(k_) / ms_, 3) if pmc_valu_busy_ms(k_) else None)}
+        if "gemm_tn_splitk" in groups and groups["gemm_tn_splitk"][0] > 0:
+            # dW = dY^T X over all rays, the two shapes of a layer: [592 x R] x [R x 128] twice per layer
+            ff = 2.0 * RA * d_feat * (heads * (d_feat + PA + (vc - 1 if vc > 2 else 0)))
+            ms_ = groups["gemm_tn_splitk"][0]
+            roofline_a["gemm_tn_splitk"] = {
+                "ms": round(ms_, 4), "gflop": round(ff / 1e9, 2), "tflops": round(ff / (ms_ * 1e-3) / 1e12, 1),
+                "bound": "mfma", "peak": VEC_PEAK, "frac_of_fp32_matrix_peak": round(ff / (ms_ * 1e-3) / 1e12 / VEC_PEAK, 4)}
+        dom = max((k for k in alg if k in groups), key=lambda k: groups[k][0])
         dom_ms = groups[dom][0]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         # committed PMC summaries exist for the three benchmarked BASELINE configurations
@@ -842,6 +935,7 @@ def main():
                                          if pmc_valu_busy_ms(g_) else None)}
                 for g_ in SINGLE_KERNEL_GROUPS
                 if is_c2 and g_ in groups and groups[g_][0] > 0 and pmc_traffic(g_)[0]},
+            "roofline_a": roofline_a,
             "step_check": check,
             "build": build_info,
             "launch": launch_mode, "launch_requested": args.launch, "launch_fallback": launch_fallback,
@@ -862,6 +956,8 @@ def main():
                 "depth_predictor_only_ms_per_step": round(ms_dp, 3),
                 # features -> head -> Gaussians -> 28 rendered views -> MSE and back
                 "head_decoder_loss_chain_ms_per_step": (round(ms_chain, 3) if ms_chain else None),
+                "connected_ms_per_step": (connected or {}).get("ms_per_step"),
+                "connected": connected,
                 "epipolar_reference_equivalent_tflops": round(
                     3.0 * 2 * (2.0 * RA * (2 * d_feat * 512 + TA * d_feat * 1024 + 2 * 4 * TA * 128))
                     / (ms_a * 1e-3) / 1e12, 1),
@@ -887,6 +983,13 @@ def main():
                 "raster_algorithmic_bytes_per_step": (1120.0 * G + 40.0 * npix) * V + 160.0 * D_total,
                 "raster_hbm_frac": round(((1120.0 * G + 40.0 * npix) * V + 160.0 * D_total)
                                          / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # BASELINE.json north_star: ">= 60 % of the MI355X HBM roofline on the raster fwd+bwd".
+                # The bar stands; the line reports the distance to it
+                "raster_hbm_frac_target": 0.60,
+                "raster_hbm_frac_gap": round(0.60 - ((1120.0 * G + 40.0 * npix) * V + 160.0 * D_total)
+                                             / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "raster_ms_at_target": round(((1120.0 * G + 40.0 * npix) * V + 160.0 * D_total)
+                                             / (0.60 * HBM_PEAK_GBS * 1e9) * 1e3, 3),
                 # the same formula with what THIS design reads / writes once per SCENE counted once per
                 # scene (the 340 B/Gaussian inputs in the forward and again in the backward, the 340
                 # B/Gaussian of gradients) instead of once per view: the contract's figure above charges
@@ -942,8 +1045,36 @@ def main():
             out["parity_vs_oracle"] = parity
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+        _STATE["printed"] = True
     P.shutdown(world)
 
 
+_STATE = {"json_out": None, "printed": False}
+
+
+def _error_line(err: BaseException) -> None:
+    """A rank that fails where the process survives (a Python exception: a peer that died inside a
+    collective, an allocation failure, a failed check) still leaves ONE JSON line on rank 0 -- value 0 and an
+    `error` field -- so that a scaling run never yields nothing to read.  (A GPU memory fault aborts the
+    process from inside the runtime: nothing can be printed then.)"""
+    if _STATE["printed"] or int(os.environ.get("RANK", "0")) != 0:
+        return
+    out = _STATE["json_out"] or sys.stdout
+    args = sys.argv[1:]
+    n = int(args[args.index("--gpus") + 1]) if "--gpus" in args and args.index("--gpus") + 1 < len(args) else 1
+    out.write(json.dumps({
+        "metric": "rendered views/sec (fwd+bwd)", "value": 0.0, "unit": "views/s",
+        "n_gpus": int(os.environ.get("WORLD_SIZE", n)), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "error": f"{type(err).__name__}: {err}"[:600], "argv": args}) + "\n")
+    out.flush()
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as err:      # noqa: BLE001 -- reported, then re-raised
+        _error_line(err)
+        raise

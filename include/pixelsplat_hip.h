@@ -69,6 +69,15 @@ typedef enum PsStatus {
  * (any time before ps_raster_forward_tiles): a host that reads D back after the plan can queue
  * it behind that copy, so the GPU evaluates colours while the host waits and allocates. */
 #define PS_FLAG_DEFER_SH_COLORS 2
+/* ps_raster_backward: deterministic gradient accumulation.  Gaussians whose rect covers more than
+ * four tiles normally sum their per-tile partial gradients through float atomics (summation order =
+ * the order in which the tiles' waves retire: run-to-run differences in the last bits).  With this flag
+ * every (tile, Gaussian) partial is stored in a slot of its own -- one per tile-list entry -- and summed by
+ * a second kernel in a fixed order (tiles of the rect, row-major): two runs are bitwise equal.  Costs
+ * 48 bytes per list entry + 4 bytes per (view, Gaussian) of backward scratch
+ * (ps_raster_backward_temp_bytes accounts for it) and a cleared slot array per call: a mode for parity /
+ * reproducibility runs ("race detection"), not the benchmarked path. */
+#define PS_FLAG_DETERMINISTIC 4
 
 typedef struct PsRasterDesc {
   int32_t n_scenes;        /* S: independent Gaussian sets                           */
@@ -534,6 +543,12 @@ const char* ps_status_string(int status);
 /* "pixelsplat_hip gfx950 <date> <time> | <file>:<hash> ..." -- one hash per translation unit over
  * its source, the shared headers and the compile flags (pixelsplat_amd/build.py). */
 const char* ps_build_info(void);
+/* Layout version of the descriptor structs of this header (PsRasterDesc, PsEpipolarDesc, ...): bumped
+ * whenever a struct grows or a field changes meaning.  A host built against an older header would hand
+ * the library shorter structs (PsEpipolarDesc grew by tail_pad_in / tail_pad_out in version 4): check
+ * ps_abi_version() == PS_ABI_VERSION once after loading (pixelsplat_amd/_lib.py does). */
+#define PS_ABI_VERSION 5
+int ps_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -112,9 +112,15 @@ class RasterizerRecorder:
     by oracle/raster_ref.c, so what comes out of the reference functions is
     "reference host glue + oracle rasterizer"."""
 
-    def __init__(self, render: bool = True):
+    def __init__(self, render: bool = True, differentiable: bool = False, keep_calls: bool = True):
+        """`differentiable`: the stand-in is an autograd function -- forward = oracle/raster_ref.c,
+        backward = its hand-written backward -- so that the reference's decoder, encoder head and
+        epipolar transformer can be chained into ONE training step on the CPU with gradients flowing
+        end to end (tests/golden/make_connected_golden.py)."""
         self.calls: list[dict] = []
         self.render = render
+        self.differentiable = differentiable
+        self.keep_calls = keep_calls
 
     def install(self):
         import typing
@@ -161,6 +167,37 @@ class RasterizerRecorder:
                     shs=npf(shs), colors_precomp=npf(colors_precomp), cov3D_precomp=npf(cov3D_precomp),
                     scales=scales, rotations=rotations)
                 h, w = call["image_height"], call["image_width"]
+                if rec.render and rec.differentiable and shs is not None and cov3D_precomp is not None:
+                    from oracle import raster_ref as R
+
+                    class _Oracle(torch.autograd.Function):
+                        @staticmethod
+                        def forward(ctx, m3, m2, op, sh_, cov_):
+                            st = R.forward(
+                                means=call["means3D"], cov6=call["cov3D_precomp"],
+                                opacity=call["opacities"][:, 0], view=call["viewmatrix"].reshape(16),
+                                proj=call["projmatrix"].reshape(16), campos=call["campos"], bg=call["bg"],
+                                H=h, W=w, tanfovx=call["tanfovx"], tanfovy=call["tanfovy"],
+                                sh=call["shs"], colors=None, sh_degree=call["sh_degree"])
+                            ctx.st = st
+                            call["image"] = st.image.copy()
+                            call["radii"] = st.radii.copy()
+                            call["ambiguous"] = R.ambiguity_mask(st)
+                            radii_ = torch.from_numpy(st.radii.copy())
+                            ctx.mark_non_differentiable(radii_)
+                            return torch.from_numpy(st.image.copy()), radii_
+
+                        @staticmethod
+                        def backward(ctx, d_img, _d_radii):
+                            g = R.backward(ctx.st, d_img.detach().cpu().numpy().astype(np.float32))
+                            f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32))
+                            return (f(g["means3D"]), f(g["means2D"]), f(g["opacity"])[:, None], f(g["sh"]),
+                                    f(g["cov6"]))
+
+                    image, radii = _Oracle.apply(means3D, means2D, opacities, shs, cov3D_precomp)
+                    if rec.keep_calls:
+                        rec.calls.append(call)
+                    return image, radii
                 if rec.render:
                     from oracle import raster_ref as R
 

@@ -16,6 +16,7 @@ PS_SH_GK3, PS_SH_G3K = 0, 1
 PS_COV_6, PS_COV_33 = 0, 1
 PS_FLAG_BWD_TEMP_ZEROED = 1
 PS_FLAG_DEFER_SH_COLORS = 2
+PS_FLAG_DETERMINISTIC = 4
 PS_VIEW_STRIDE = 48
 PS_VIEW_VIEWMATRIX, PS_VIEW_PROJMATRIX, PS_VIEW_CAMPOS = 0, 16, 32
 PS_VIEW_TANFOVX, PS_VIEW_TANFOVY, PS_VIEW_BG, PS_VIEW_SCALE = 35, 36, 37, 40
@@ -80,7 +81,9 @@ EXPORTS = [
     "ps_image_mse_workspace_bytes", "ps_image_mse", "ps_depth_smoothness_workspace_bytes",
     "ps_depth_smoothness_forward", "ps_depth_smoothness_backward",
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
+    "ps_abi_version",
 ]
+PS_ABI_VERSION = 5      # include/pixelsplat_hip.h
 
 _lib = None
 
@@ -107,6 +110,11 @@ def load():
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise HipExtensionMissing(f"{LIB_PATH} does not export {name}")
+    lib.ps_abi_version.restype = C.c_int
+    if lib.ps_abi_version() != PS_ABI_VERSION:
+        raise HipExtensionMissing(
+            f"{LIB_PATH} has descriptor layout version {lib.ps_abi_version()}, this package expects "
+            f"{PS_ABI_VERSION}: rebuild it with `python -m pixelsplat_amd.build`")
     vp = C.c_void_p
     lib.ps_raster_default_desc.argtypes = [C.POINTER(PsRasterDesc)]
     lib.ps_raster_default_desc.restype = None

@@ -15,14 +15,14 @@ namespace {
 // ---- optional per-kernel-group timing (bench.py) ----------------------------------------
 enum Group { G_PRE_FWD = 0, G_SORT, G_BINS, G_TILES_FWD, G_TILES_BWD, G_PRE_BWD, G_MEMSET,
              G_EPI_GEOM, G_EPI_FWD, G_EPI_BWD, G_EPI_FGRAD, G_GEMM_TN, G_ADAPTER_FWD, G_ADAPTER_BWD,
-             G_DEPTH_FWD, G_DEPTH_BWD, G_LOSS, G_COUNT };
+             G_DEPTH_FWD, G_DEPTH_BWD, G_LOSS, G_TASK_ORDER, G_COUNT };
 const char* kGroupNames[G_COUNT] = {"preprocess_forward", "depth_sort", "tile_bins", "tiles_forward",
                                     "tiles_backward", "preprocess_backward", "memset",
                                     "epipolar_geometry", "epipolar_attention_forward",
                                     "epipolar_attention_backward", "epipolar_feature_grad",
                                     "gemm_tn_splitk", "gaussian_adapter_forward",
                                     "gaussian_adapter_backward", "depth_sampler_forward",
-                                    "depth_sampler_backward", "image_losses"};
+                                    "depth_sampler_backward", "image_losses", "backward_task_order"};
 std::atomic<int> g_profile_on{0};     // bit 0: HIP events per group, bit 1: roctx ranges per group
 std::mutex g_profile_mu;
 struct Pending { hipEvent_t a, b; int group; };
@@ -62,7 +62,7 @@ const char* kRangeNames[] = {"ps:preprocess_forward", "ps:depth_sort", "ps:tile_
                              "ps:epipolar_attention_backward", "ps:epipolar_feature_grad",
                              "ps:gemm_tn_splitk", "ps:gaussian_adapter_forward",
                              "ps:gaussian_adapter_backward", "ps:depth_sampler_forward",
-                             "ps:depth_sampler_backward", "ps:image_losses"};
+                             "ps:depth_sampler_backward", "ps:image_losses", "ps:backward_task_order"};
 static_assert(sizeof(kRangeNames) / sizeof(kRangeNames[0]) == G_COUNT, "one range name per group");
 
 struct Scope {
@@ -295,18 +295,35 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   float* grad2d = (float*)(tb + T.grad2d);
   float* tile_grads = (float*)(tb + T.tile_grads);
   uint32_t* task_order = (uint32_t*)(tb + T.task_order);
+  const bool deterministic = (d->flags & PS_FLAG_DETERMINISTIC) != 0;
+  float* det_slots = deterministic ? (float*)(tb + T.det_slots) : nullptr;
   {
     Scope sc(G_MEMSET, st);
     // only the grad2d rows the tile backward adds into with atomics (pairs over > kInvSlots
     // tiles); the private slots are written exactly once each and need no clearing
-    if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
-    // the tile backward's tasks, longest WALK first (the forward left every tile's last contributor)
+    if (deterministic) {      // no atomics: the per-entry slots start from zero instead
+      if (capacity > 0 &&
+          hipMemsetAsync(det_slots, 0, (size_t)capacity * kSlotFloats * 4, st) != hipSuccess)
+        return PS_ERR_LAUNCH;
+    } else if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
+      launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
+    }
+  }
+  {
+    // the tile backward's tasks, longest WALK first (the forward left every tile's last contributor);
+    // a group of its own (it used to be timed inside `memset`)
+    Scope sc(G_TASK_ORDER, st);
     launch_backward_task_order(*d, tile_ranges, tile_end, capacity, task_order, st);
   }
   {
     Scope sc(G_TILES_BWD, st);
     launch_tiles_backward(*d, records, task_order, tile_ranges, point_list, capacity, view_params,
-                          final_T, n_contrib, checkpoint, tile_end, dL_dcolor, grad2d, tile_grads, st);
+                          final_T, n_contrib, checkpoint, tile_end, dL_dcolor, grad2d, tile_grads,
+                          det_slots, st);
+    if (deterministic)
+      launch_deterministic_reduce(*d, radii, rects, (const uint32_t*)(sb + L.sorted_idx),
+                                  (const uint32_t*)(sb + L.n_vis), tile_ranges, point_list, capacity,
+                                  det_slots, (uint32_t*)(tb + T.rank_of), grad2d, st);
   }
   {
     Scope sc(G_PRE_BWD, st);
@@ -360,6 +377,14 @@ bool epi_ok(const PsEpipolarDesc* d) {
          d->heads > 0 && d->octaves > 0 && d->tail_pad_in >= 0 && d->tail_pad_in <= 3 &&
          d->tail_pad_out >= 0 && d->tail_pad_out <= 3;
 }
+// the zero-filled padding behind a head's last block must lie inside the head's stride: a pad without a
+// custom stride, or one that reaches into the next head's block (a host passing a struct of an older
+// layout hands over garbage here), would silently zero live data
+bool pad_ok(const PsEpipolarDesc* d, bool with_e) {
+  const int used = d->c + 2 * d->octaves + (with_e ? d->v - 1 : 0);
+  auto one = [&](int pad, int hs) { return pad == 0 || (hs > 0 && used + pad <= hs); };
+  return one(d->tail_pad_in, d->hs_in) && one(d->tail_pad_out, d->hs_out);
+}
 AttnDims to_dims(const PsEpipolarDesc* d) {
   const int P = 2 * d->octaves, ov = d->v - 1, H = d->heads;
   auto ld = [](int given, int dflt) { return given > 0 ? given : dflt; };
@@ -387,7 +412,7 @@ int ps_epipolar_attention_forward(const PsEpipolarDesc* d, const float* fmap,
                                   const float* e, float scale, float* fbar, float* pbar,
                                   float* abar, float* attn, void* stream) {
   if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !u || !fbar ||
-      !pbar || !abar || !attn)
+      !pbar || !abar || !attn || !pad_ok(d, e != nullptr))
     return PS_ERR_BAD_ARG;
   Scope sc(G_EPI_FWD, (hipStream_t)stream);
   if (int rc = launch_epipolar_attn_forward(to_dims(d), fmap, xy_sample, flags, rel_disparity,
@@ -406,7 +431,8 @@ int ps_epipolar_attention_backward(const PsEpipolarDesc* d, const float* fmap,
                                    float* de, float* ds, float* dfmap, uint32_t* ray_boxes,
                                    void* stream) {
   if (!epi_ok(d) || !fmap || !xy_sample || !flags || !rel_disparity || !qt || !attn || !fbar ||
-      !pbar || !dfbar || !dpbar || !dqt || !du || !ds || (dfmap && !ray_boxes))
+      !pbar || !dfbar || !dpbar || !dqt || !du || !ds || (dfmap && !ray_boxes) ||
+      !pad_ok(d, de != nullptr))
     return PS_ERR_BAD_ARG;
   {
     Scope sc(G_EPI_BWD, (hipStream_t)stream);
@@ -809,6 +835,8 @@ int ps_profile_collect(double* total_ms, int64_t* launches) {
   }
   return rc;
 }
+
+int ps_abi_version(void) { return PS_ABI_VERSION; }
 
 const char* ps_status_string(int status) {
   switch (status) {

@@ -368,6 +368,73 @@ void launch_clear_atomic_rows(const PsRasterDesc& d, const int32_t* radii, const
                      (d.height + kTile - 1) / kTile, radii, rects, grad2d);
 }
 
+// ---- PS_FLAG_DETERMINISTIC -------------------------------------------------------------------------
+// rank_of[v][id] = position of the Gaussian in its view's (depth, id) order: the order of every tile list
+__global__ void __launch_bounds__(256)
+det_rank_kernel(int G, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ n_vis,
+                uint32_t* __restrict__ rank_of) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  const size_t vo = (size_t)blockIdx.y * G;
+  if (r < n_vis[blockIdx.y]) rank_of[vo + sorted_idx[vo + r]] = r;
+}
+
+// One thread per visible (view, Gaussian) pair over more than kInvSlots tiles: the tiles of its rect in
+// row-major order; in each, its entry is found by bisection on the ranks (a tile list is sorted by rank)
+// and the slot the tile backward left there is added.  Fixed order, no atomics: bitwise reproducible.
+__global__ void __launch_bounds__(256)
+det_reduce_kernel(size_t n, int G, int gx, int gy, const int32_t* __restrict__ radii,
+                  const uint2* __restrict__ rects, const uint32_t* __restrict__ rank_of,
+                  const uint32_t* __restrict__ tile_ranges, const uint32_t* __restrict__ point_list,
+                  uint32_t capacity, const float4* __restrict__ det_slots, float* __restrict__ grad2d) {
+  const size_t vg = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (vg >= n) return;
+  if (radii[vg] <= 0) return;
+  const uint2 r = rects[vg];
+  const uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu, ymax = r.y >> 16;
+  if ((xmax - xmin) * (ymax - ymin) <= (uint32_t)kInvSlots && gy <= 16383) return;   // private slots
+  const size_t v = vg / (size_t)G, vo = v * (size_t)G;
+  const uint32_t id = (uint32_t)(vg - vo), my = rank_of[vg];
+  float acc[kGradFloats];
+#pragma unroll
+  for (int c = 0; c < kGradFloats; ++c) acc[c] = 0.f;
+  for (uint32_t ty = ymin; ty < ymax; ++ty)
+    for (uint32_t tx = xmin; tx < xmax; ++tx) {
+      const size_t tile = v * (size_t)(gx * gy) + (size_t)ty * gx + tx;
+      uint32_t start = tile_ranges[2 * tile], cnt = tile_ranges[2 * tile + 1];
+      if (start > capacity) start = capacity;
+      if (cnt > capacity - start) cnt = capacity - start;
+      const uint32_t* list = point_list + start;
+      uint32_t lo = 0, hi = cnt;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rank_of[vo + list[mid]] < my) lo = mid + 1; else hi = mid;
+      }
+      if (lo < cnt && list[lo] == id) {
+        const float4* s = det_slots + ((size_t)start + lo) * (kSlotFloats / 4);
+        const float4 a = s[0], b = s[1], c = s[2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x;
+      }
+    }
+  float* g = grad2d + vg * kGradFloats;
+#pragma unroll
+  for (int c = 0; c < kGradFloats; ++c) g[c] = acc[c];
+}
+
+void launch_deterministic_reduce(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
+                                 const uint32_t* sorted_idx, const uint32_t* n_vis,
+                                 const uint32_t* tile_ranges, const uint32_t* point_list,
+                                 uint32_t capacity, const float* det_slots, uint32_t* rank_of,
+                                 float* grad2d, hipStream_t st) {
+  const Dims m = make_dims(d);
+  if (m.N == 0) return;
+  hipLaunchKernelGGL(det_rank_kernel, dim3((unsigned)((m.G + 255) / 256), (unsigned)m.V), dim3(256), 0, st,
+                     m.G, sorted_idx, n_vis, rank_of);
+  hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((m.N + 255) / 256)), dim3(256), 0, st, m.N, m.G,
+                     m.gx, m.gy, radii, rects, rank_of, tile_ranges, point_list, capacity,
+                     reinterpret_cast<const float4*>(det_slots), grad2d);
+}
+
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,

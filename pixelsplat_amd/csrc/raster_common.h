@@ -78,7 +78,7 @@ inline TempLayout make_temp_layout(const PsRasterDesc& d) {
 // clears the rows in use itself, ps_raster_backward_prepare clears all of it); color_grads is the compact
 // per-(view, Gaussian) dL/dRGB the geometry backward hands to the SH backward (12 B rows
 // instead of 3 floats out of every 36-byte grad2d row and 1 out of every 48-byte record)
-struct BwdTempLayout { size_t grad2d, tile_grads, zeroed, color_grads, task_order, total; };
+struct BwdTempLayout { size_t grad2d, tile_grads, zeroed, color_grads, task_order, det_slots, rank_of, total; };
 inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_capacity) {
   const Dims m = make_dims(d);
   BwdTempLayout t; size_t o = 0;
@@ -86,11 +86,17 @@ inline BwdTempLayout make_bwd_temp_layout(const PsRasterDesc& d, size_t list_cap
   t.zeroed = o;   // only the atomic accumulators need clearing
   // one private slot per (view, Gaussian, tile of its <= 4-tile rect): every one is written
   // exactly once by the tile backward (values or zeros), so no memset and no position map
-  (void)list_capacity;
   t.tile_grads = o; o = align_up(o + m.N * kInvSlots * kSlotFloats * 4);
   t.color_grads = o; o = align_up(o + m.N * 3 * 4);
   // launch order of the tile backward's 2 tasks per tile, longest walk first (raster_tiles.hip)
   t.task_order = o; o = align_up(o + (size_t)m.V * m.tiles * 2 * 4);
+  // PS_FLAG_DETERMINISTIC: one slot per tile-list entry for the partial gradients of the Gaussians over
+  // more than kInvSlots tiles (no float atomics), and every visible pair's rank in its view's depth order
+  t.det_slots = t.rank_of = o;
+  if (d.flags & PS_FLAG_DETERMINISTIC) {
+    t.det_slots = o; o = align_up(o + list_capacity * kSlotFloats * 4);
+    t.rank_of = o; o = align_up(o + m.N * 4);
+  }
   t.total = o;
   return t;
 }
@@ -150,7 +156,13 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const float4* checkpoint,
                            const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
-                           float* tile_grads, hipStream_t st);
+                           float* tile_grads, float* det_slots, hipStream_t st);
+// PS_FLAG_DETERMINISTIC: ranks, then the fixed-order sum of the per-entry slots into grad2d
+void launch_deterministic_reduce(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
+                                 const uint32_t* sorted_idx, const uint32_t* n_vis,
+                                 const uint32_t* tile_ranges, const uint32_t* point_list,
+                                 uint32_t capacity, const float* det_slots, uint32_t* rank_of,
+                                 float* grad2d, hipStream_t st);
 
 void launch_clear_atomic_rows(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
                               float* grad2d, hipStream_t st);

@@ -409,8 +409,6 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
       ck[k * kWave] = make_float4(c.x, (C0[k] - c.y) * inv, (C1[k] - c.z) * inv, (C2[k] - c.w) * inv);
     }
   }
-  // the tile's last contributor (informational since the backward derives it from n_contrib;
-  // with several waves per tile only the one-wave-per-tile build writes it)
   // the tile's last contributor (both half-tile waves max into it; cleared by the binning's scan kernel):
   // the backward orders its tasks by it and starts its walks there
   max_c = wave_max_u(max_c);
@@ -479,6 +477,9 @@ __device__ __forceinline__ void wave_sum9_partials(float a, float b, float c, fl
 // min(alpha_max, .) is one instruction, two entries per trip with each record read from LDS while the
 // other entry is processed.  Held to 4 waves per SIMD (128 VGPRs): 3 waves with 168 registers measured
 // slower (2.17 ms).
+// DET (PS_FLAG_DETERMINISTIC): the partial gradient of a Gaussian over more than kInvSlots tiles goes to the
+// slot of its list entry (det_slots[list position], cleared by the caller) instead of nine float atomics.
+template <bool DET>
 __global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, 4)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ task_order,
@@ -488,7 +489,8 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ n_contrib,
                       const float4* __restrict__ checkpoint,
                       const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
-                      float* __restrict__ grad2d, float* __restrict__ tile_grads) {
+                      float* __restrict__ grad2d, float* __restrict__ tile_grads,
+                      float4* __restrict__ det_slots) {
   __shared__ WaveLdsBwd lds_all[kWavesPerBlockBwd];
   const int G = d.n_gaussians, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
@@ -634,8 +636,8 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     {
       const uint64_t npm = __ballot(not_plain);
       if (npm) {
-        const int hi = 63 - __builtin_clzll(npm);
-        np_end = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask & ((2ull << hi) - 1ull)));
+        const int top_lane = 63 - __builtin_clzll(npm);
+        np_end = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask & ((2ull << top_lane) - 1ull)));
       }
     }
     if (keep) {
@@ -770,6 +772,13 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
         tg[1] = hit ? make_float4(o4, s_op, s_r, s_g) : make_float4(0.f, 0.f, 0.f, 0.f);
         tg[2] = make_float4(hit ? s_b : 0.f, 0.f, 0.f, 0.f);
         if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (DET) {
+        if (hit) {      // (entries that never get here keep the zeros the caller cleared the slots to)
+          float4* ds = det_slots + ((size_t)l_start + (__float_as_uint(q2.y) - 1u)) * kSlotVec;
+          ds[0] = make_float4(o0, o1, o2, o3);
+          ds[1] = make_float4(o4, s_op, s_r, s_g);
+          ds[2] = make_float4(s_b, 0.f, 0.f, 0.f);
+        }
       } else if (hit) {
         float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
         atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
@@ -902,13 +911,18 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const float4* checkpoint,
                            const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
-                           float* tile_grads, hipStream_t st) {
+                           float* tile_grads, float* det_slots, hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = 2 * m.V * m.tiles;
   dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
-  hipLaunchKernelGGL(tiles_backward_kernel, grid, block, 0, st, d, records, task_order, tile_ranges,
-                     point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
-                     dL_dcolor, grad2d, tile_grads);
+  if (det_slots != nullptr)
+    hipLaunchKernelGGL(tiles_backward_kernel<true>, grid, block, 0, st, d, records, task_order, tile_ranges,
+                       point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
+                       dL_dcolor, grad2d, tile_grads, reinterpret_cast<float4*>(det_slots));
+  else
+    hipLaunchKernelGGL(tiles_backward_kernel<false>, grid, block, 0, st, d, records, task_order, tile_ranges,
+                       point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
+                       dL_dcolor, grad2d, tile_grads, (float4*)nullptr);
 }
 
 }  // namespace ps

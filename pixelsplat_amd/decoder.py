@@ -73,7 +73,7 @@ def _view_params_torch(extrinsics, near, far, fov_x, fov_y, tan_fov, background_
 
 
 def _render(vp, image_shape, gaussian_means, gaussian_covariances, gaussian_sh_coefficients,
-            gaussian_opacities, use_sh, views_per_scene, return_aux, list_capacity=0):
+            gaussian_opacities, use_sh, views_per_scene, return_aux, list_capacity=0, deterministic=None):
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     v_total = vp.shape[0]
     s, g, _ = gaussian_means.shape
@@ -83,7 +83,8 @@ def _render(vp, image_shape, gaussian_means, gaussian_covariances, gaussian_sh_c
     degree = isqrt(n) - 1
     cfg = RasterConfig(n_scenes=s, views_per_scene=views_per_scene, n_gaussians=g, height=h,
                        width=w, sh_degree=degree if use_sh else 0, sh_coeffs=n if use_sh else 0,
-                       sh_layout=PS_SH_G3K, cov_layout=PS_COV_33, list_capacity=int(list_capacity))
+                       sh_layout=PS_SH_G3K, cov_layout=PS_COV_33, list_capacity=int(list_capacity),
+                       deterministic=deterministic)
     if use_sh:
         sh, colors = gaussian_sh_coefficients, None
     else:
@@ -110,7 +111,8 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
                 gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
                 gaussian_opacities: Tensor, scale_invariant: bool = True, use_sh: bool = True,
                 views_per_scene: int = 1, return_aux: bool = False,
-                view_params: Tensor | None = None, list_capacity: int = 0):
+                view_params: Tensor | None = None, list_capacity: int = 0,
+                deterministic: bool | None = None):
     """[B,4,4] c2w, [B,3,3], [B], [B], (h,w), [B,3], Gaussians [B/vps, G, ...] -> [B,3,h,w].
 
     With views_per_scene == 1 the call is argument-for-argument the reference's
@@ -120,12 +122,15 @@ def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
     settings recorded from the reference's own host code.  `list_capacity` > 0 fixes the size of
     the tile point list up front (entries, all views together): no host synchronisation in the
     call, which is what hipGraph capture of a training step needs; an overflow raises from
-    backward() (or from `pixelsplat_amd.raster.captured_overflow_flags()` after a graph replay)."""
+    backward() (or from `pixelsplat_amd.raster.captured_overflow_flags()` after a graph replay).
+    `deterministic=True`: the backward sums the gradients of Gaussians over more than four tiles in a
+    fixed order instead of through float atomics (PS_FLAG_DETERMINISTIC; default: the
+    PIXELSPLAT_DETERMINISTIC environment variable, off)."""
     vp = view_params if view_params is not None else camera_setup(
         extrinsics, intrinsics, near, far, background_color, scale_invariant)
     return _render(vp, image_shape, gaussian_means, gaussian_covariances,
                    gaussian_sh_coefficients, gaussian_opacities, use_sh, views_per_scene,
-                   return_aux, list_capacity)
+                   return_aux, list_capacity, deterministic)
 
 
 def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor,

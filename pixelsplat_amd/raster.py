@@ -58,6 +58,10 @@ class RasterConfig:
     # 0: size the tile point list exactly (one 8-byte host read-back per call);
     # > 0: fixed capacity in entries, no host sync, overflow raises from backward()
     list_capacity: int = 0
+    # gradients of Gaussians over more than four tiles summed in a fixed order instead of through float
+    # atomics (PS_FLAG_DETERMINISTIC: two runs are bitwise equal; more scratch, slower -- for parity and
+    # reproducibility runs).  None: the PIXELSPLAT_DETERMINISTIC environment variable decides (default off)
+    deterministic: bool | None = None
 
     def desc(self) -> _lib.PsRasterDesc:
         d = _lib.default_desc()
@@ -66,6 +70,12 @@ class RasterConfig:
         d.height, d.width = self.height, self.width
         d.sh_degree, d.sh_coeffs = self.sh_degree, self.sh_coeffs
         d.sh_layout, d.cov_layout = self.sh_layout, self.cov_layout
+        det = self.deterministic
+        if det is None:
+            import os
+            det = os.environ.get("PIXELSPLAT_DETERMINISTIC", "0") not in ("", "0")
+        if det:
+            d.flags |= _lib.PS_FLAG_DETERMINISTIC
         return d
 
     @property

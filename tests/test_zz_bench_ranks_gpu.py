@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*extra):
+def _bench(*extra, steps=3):
     env = dict(os.environ, PIXELSPLAT_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1",
            "--size", "64", "--batch", "1", "--no-cpu-baseline", "--no-probes", *extra]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -32,6 +32,7 @@ def _bench(*extra):
 def test_two_ranks_on_one_device(gpu_device, mode):
     rec = _bench("--launch", mode)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["step_check"]["ok"] and rec["step_check"]["ranks"] == 2, rec["step_check"]
     comm = rec["comm"]
     assert comm["world_size"] == 2 and comm["rccl_nranks"] == 2 and comm["backend"] == "gloo"
     assert len(comm["rank_ms_per_step"]["all"]) == 2
@@ -49,3 +50,23 @@ def test_two_ranks_on_one_device(gpu_device, mode):
         if rec["launch"] == "eager":
             assert rec["launch_fallback"]                  # a fallback must say why
         assert rec["paths"]["eager_ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("mode", ["eager", "auto"])
+def test_two_ranks_200_steps_reduced_gradients_are_the_mean_of_the_ranks(gpu_device, mode):
+    """The stress form of the test above: 200 timed steps per launch mode, different
+    batches per rank (per-rank seeds), and bench.py's `step_check` on the state the LAST step left behind:
+    the reduced parameter gradients must equal the mean over the two ranks of what each computes on its own in
+    one eager step without the reducer (1e-6 of max: one rounding of the mean), the rasterizer's and the
+    feature map's gradients and the tokens / image of the replayed step those of that eager step.  Round 4's
+    memory fault (profiles/r5_fault_root_cause.txt) hit 4 of 5 such runs within 40 steps."""
+    rec = _bench("--launch", mode, steps=200)
+    chk = rec["step_check"]
+    assert chk["ok"], chk
+    assert chk["ranks"] == 2 and chk["steps_before_the_check"] == 201
+    assert chk["max_err"]["d_parameters_reduced"] <= 1e-6 and chk["max_err"]["d_features"] <= 1e-6
+    assert chk["max_err"]["tokens_out"] == 0.0 and chk["max_err"]["image_vs_this_eager_step"] == 0.0
+    if mode == "auto":
+        assert rec["launch"] == "hipgraph", rec.get("launch_fallback")
+    comm = rec["comm"]
+    assert comm["launches_total_at_end_of_timed_region"] >= 200 * comm["buckets"]

@@ -90,6 +90,7 @@ def test_bench_step_beside_a_live_rccl_communicator(gpu_device, mode):
     rec = _last_json(subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT))
     comm = rec["comm"]
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["step_check"]["ok"], rec["step_check"]
     assert comm["backend"] == "nccl" and comm["forced_one_rank_communicator"] and comm["rccl_nranks"] == 1
     assert comm["buckets"] >= 1 and comm["launches_total_at_end_of_timed_region"] >= 4 * comm["buckets"]
     assert comm["extra_payload_bytes_per_step"] == 16_000_000
