@@ -6,9 +6,10 @@ build container with the oracle rasterizer (forward and backward) standing in fo
 (tests/golden/make_connected_golden.py -> tests/golden/connected.npz).
 
 Tolerances.  The continuous part of the chain is held to fp32 GEMM / transcendental noise, per tensor relative
-to its largest entry:  transformer output 2e-4 (the reference's own float32-vs-float64 noise through its
-per-sample 3x3 lstsq and the 2 pi 2^9 gain of the depth encoding is ~1e-3 on the attention output),
-Gaussian parameters 1e-3 outside the few Gaussians whose depth BUCKET differs.  The uniforms of the golden
+to its largest entry:  transformer output 2e-3 worst / 1e-4 mean (the reference's own float32-vs-float64 noise
+through its per-sample 3x3 lstsq and the 2 pi 2^9 gain of the depth encoding is 1.1e-3 on the attention output,
+DESIGN.md 2; measured here: 4.8e-4), Gaussian parameters 5e-3 / 1e-4 outside the few Gaussians whose depth BUCKET
+differs.  The uniforms of the golden
 sit >= 2e-3 away from every CDF edge of the reference chain, so bucket flips need a CDF error of that size; they
 are counted and must be < 0.1 % of the draws.  The rasterizer then makes discrete decisions on inputs that
 differ in the last digits (radius = ceil(3 sigma), alpha >= 1/255, T < 1e-4): the image is held to 2e-3 at the
@@ -77,27 +78,38 @@ def test_connected_step_vs_reference_chain(gpu_device):
     out.loss.backward()
     torch.cuda.synchronize()
 
+    bad = []          # every check runs; the failures are reported together
+
+    def check(ok, msg):
+        if not ok:
+            bad.append(msg)
+
     # --- forward, stage by stage ---
     worst, mean = _rel(out.features, g["transformer_out"])
-    assert worst < 2e-4, f"transformer output {worst:.2e}"
+    check(worst < 2e-3 and mean < 1e-4, f"transformer output worst {worst:.2e} mean {mean:.2e}")
+    fwd_report = [("transformer_out", worst, mean)]
     gm = out.gaussians.means.detach().cpu()
     moved = ((gm - torch.from_numpy(g["g_means"])).abs().amax(-1)
              > 1e-3 * torch.from_numpy(g["g_means"]).abs().amax(-1).clamp_min(1e-3))[0]
     n_moved = int(moved.sum())
-    assert n_moved < 1e-3 * moved.numel(), f"{n_moved} Gaussians landed in another depth bucket"
+    check(n_moved < 1e-3 * moved.numel(), f"{n_moved} Gaussians landed in another depth bucket")
     keep = ~moved
     for name, a, key in (("means", out.gaussians.means, "g_means"), ("cov", out.gaussians.covariances, "g_cov"),
                          ("opacity", out.gaussians.opacities, "g_op")):
-        w_, _ = _rel(a[0][keep.to(a.device)], torch.from_numpy(g[key])[0][keep])
-        assert w_ < 1e-3, f"{name}: {w_:.2e}"
-    w_, _ = _rel(out.gaussians.harmonics[0, :2048][keep[:2048].to(dev)],
-                 torch.from_numpy(g["g_sh_first_2048"])[0][keep[:2048]])
-    assert w_ < 1e-3, f"harmonics: {w_:.2e}"
+        w_, m_ = _rel(a[0][keep.to(a.device)], torch.from_numpy(g[key])[0][keep])
+        fwd_report.append((name, w_, m_))
+        check(w_ < 5e-3 and m_ < 1e-4, f"gaussians.{name}: worst {w_:.2e} mean {m_:.2e}")
+    w_, m_ = _rel(out.gaussians.harmonics[0, :2048][keep[:2048].to(dev)],
+                  torch.from_numpy(g["g_sh_first_2048"])[0][keep[:2048]])
+    fwd_report.append(("harmonics", w_, m_))
+    check(w_ < 5e-3 and m_ < 1e-4, f"gaussians.harmonics: worst {w_:.2e} mean {m_:.2e}")
 
     img = out.color.detach().cpu()
     err = (img - torch.from_numpy(g["image"])).abs().flatten()
-    assert float(err.quantile(0.999)) < 2e-3 and float(err.max()) < 5e-2, (float(err.quantile(0.999)), float(err.max()))
-    assert abs(float(out.loss) - float(g["loss"])) < 1e-4 * float(g["loss"])
+    p999, emax = float(err.quantile(0.999)), float(err.max())
+    check(p999 < 2e-3 and emax < 5e-2, f"image: p99.9 {p999:.2e} max {emax:.2e}")
+    dloss = abs(float(out.loss) - float(g["loss"])) / float(g["loss"])
+    check(dloss < 1e-4, f"loss: {dloss:.2e} relative")
 
     # --- backward: the rasterizer's gradients, the head's, the transformer's, the features' ---
     checks = [("d gaussians.means", out.gaussians.means.grad, g["grad_g_means"]),
@@ -109,21 +121,26 @@ def test_connected_step_vs_reference_chain(gpu_device):
     for prefix, mod in mods.items():
         for name, p in mod.named_parameters():
             ref = g[f"grad.{prefix}.{name}"]
-            if np.abs(ref).max() == 0.0:       # unused by this chain (e.g. nothing): must be None or zero here too
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            if np.abs(ref).max() == 0.0:       # unused by this chain: must be None or zero here too
+                check(p.grad is None or float(p.grad.abs().max()) == 0.0, f"{name}: gradient where the reference has none")
                 continue
-            assert p.grad is not None, f"no gradient reached {prefix}.{name}"
+            if p.grad is None:
+                check(False, f"no gradient reached {prefix}.{name}")
+                continue
             checks.append((f"d {prefix}.{name}", p.grad, ref))
             n_params += 1
-    assert n_params > 40
+    check(n_params > 40, f"only {n_params} parameters compared")
     report = []
     for name, a, ref in checks:
         w_, m_ = _rel(a, ref)
         report.append((w_, m_, name))
-        assert w_ < 2e-2 and m_ < 1e-3, f"{name}: worst {w_:.2e} mean {m_:.2e}"
+        check(w_ < 2e-2 and m_ < 1e-3, f"{name}: worst {w_:.2e} mean {m_:.2e}")
     report.sort(reverse=True)
-    print("connected step: worst gradient errors (worst, mean, tensor):", report[:4],
-          "; image p99.9", float(err.quantile(0.999)), "max", float(err.max()), "; moved", n_moved)
+    print("\nconnected step: forward (tensor, worst, mean):", [(n_, float(f"{a_:.2e}"), float(f"{b_:.2e}")) for n_, a_, b_ in fwd_report],
+          "\n  image p99.9", p999, "max", emax, "loss rel", dloss, "; Gaussians in another bucket:", n_moved,
+          "\n  worst gradient errors (worst, mean, tensor):", [(float(f"{a_:.2e}"), float(f"{b_:.2e}"), n_) for a_, b_, n_ in report[:6]],
+          "\n  parameters compared:", n_params)
+    assert not bad, "\n".join(bad)
 
 
 def test_connected_step_is_deterministic_and_replayable(gpu_device):
