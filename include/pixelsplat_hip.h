@@ -78,15 +78,6 @@ typedef enum PsStatus {
  * (ps_raster_backward_temp_bytes accounts for it) and a cleared slot array per call: a mode for parity /
  * reproducibility runs ("race detection"), not the benchmarked path. */
 #define PS_FLAG_DETERMINISTIC 4
-/* The tile forward records, per tile-list entry, in which 8x8 quadrants of the tile a pixel actually took
- * the entry, and the tile backward evaluates exactly those (instead of re-deriving a conservative
- * ellipse-vs-quadrant bound: ~10 % fewer quadrant evaluations, results bitwise equal).  The masks live
- * BEHIND the point list: with this flag the `point_list` buffer handed to ps_raster_forward_bins /
- * _tiles / _render / ps_raster_forward / ps_raster_backward must hold
- * ps_raster_point_list_bytes(desc, list_capacity) bytes (list_capacity u32 entries, then 2 x
- * list_capacity mask bytes from the next 16-byte boundary), and the same list_capacity must be passed to
- * the forward and the backward.  Without the flag the buffer is list_capacity u32 entries as before. */
-#define PS_FLAG_CONTRIB_MASKS 8
 
 typedef struct PsRasterDesc {
   int32_t n_scenes;        /* S: independent Gaussian sets                           */
@@ -136,7 +127,6 @@ void ps_raster_default_desc(PsRasterDesc* desc);
 size_t ps_raster_state_bytes(const PsRasterDesc* desc); /* lives from forward to backward */
 size_t ps_raster_temp_bytes(const PsRasterDesc* desc);  /* scratch of one forward call    */
 size_t ps_raster_backward_temp_bytes(const PsRasterDesc* desc, size_t list_capacity);
-size_t ps_raster_point_list_bytes(const PsRasterDesc* desc, size_t list_capacity);  /* see PS_FLAG_CONTRIB_MASKS */
 int ps_raster_state_layout(const PsRasterDesc* desc, PsRasterStateLayout* out);
 
 /* Forward.  Replaces GaussianRasterizer.forward (cuda_splatting.py:117-124).

@@ -17,7 +17,6 @@ PS_COV_6, PS_COV_33 = 0, 1
 PS_FLAG_BWD_TEMP_ZEROED = 1
 PS_FLAG_DEFER_SH_COLORS = 2
 PS_FLAG_DETERMINISTIC = 4
-PS_FLAG_CONTRIB_MASKS = 8
 PS_VIEW_STRIDE = 48
 PS_VIEW_VIEWMATRIX, PS_VIEW_PROJMATRIX, PS_VIEW_CAMPOS = 0, 16, 32
 PS_VIEW_TANFOVX, PS_VIEW_TANFOVY, PS_VIEW_BG, PS_VIEW_SCALE = 35, 36, 37, 40
@@ -68,7 +67,7 @@ class PsDepthLossDesc(C.Structure):
 # every symbol include/pixelsplat_hip.h declares
 EXPORTS = [
     "ps_raster_default_desc", "ps_raster_state_bytes", "ps_raster_temp_bytes",
-    "ps_raster_backward_temp_bytes", "ps_raster_point_list_bytes",
+    "ps_raster_backward_temp_bytes",
     "ps_raster_state_layout", "ps_raster_forward", "ps_raster_forward_plan",
     "ps_raster_forward_render", "ps_raster_forward_colors", "ps_raster_forward_bins", "ps_raster_forward_tiles", "ps_raster_backward", "ps_raster_backward_prepare",
     "ps_raster_check", "ps_camera_setup", "ps_epipolar_geometry", "ps_epipolar_gather",
@@ -125,8 +124,6 @@ def load():
     lib.ps_raster_temp_bytes.restype = C.c_size_t
     lib.ps_raster_backward_temp_bytes.argtypes = [C.POINTER(PsRasterDesc), C.c_size_t]
     lib.ps_raster_backward_temp_bytes.restype = C.c_size_t
-    lib.ps_raster_point_list_bytes.argtypes = [C.POINTER(PsRasterDesc), C.c_size_t]
-    lib.ps_raster_point_list_bytes.restype = C.c_size_t
     lib.ps_raster_state_layout.argtypes = [C.POINTER(PsRasterDesc), C.POINTER(PsRasterStateLayout)]
     lib.ps_raster_state_layout.restype = C.c_int
     lib.ps_raster_forward.argtypes = [C.POINTER(PsRasterDesc)] + [vp] * 8 + [

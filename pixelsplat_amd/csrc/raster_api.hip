@@ -118,9 +118,6 @@ size_t ps_raster_temp_bytes(const PsRasterDesc* d) {
 size_t ps_raster_backward_temp_bytes(const PsRasterDesc* d, size_t list_capacity) {
   return desc_ok(d) ? make_bwd_temp_layout(*d, list_capacity).total : 0;
 }
-size_t ps_raster_point_list_bytes(const PsRasterDesc* d, size_t list_capacity) {
-  return desc_ok(d) ? point_list_bytes(*d, list_capacity) : 0;
-}
 int ps_raster_state_layout(const PsRasterDesc* d, PsRasterStateLayout* out) {
   if (!desc_ok(d) || !out) return PS_ERR_BAD_ARG;
   *out = make_state_layout(*d);
@@ -236,16 +233,10 @@ int ps_raster_forward_tiles(const PsRasterDesc* d, const float* view_params, flo
   if (int rc = check_sizes(*d, state_bytes, temp_bytes)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FwdPtrs p = fwd_ptrs(*d, state, temp);
-  const uint32_t cap = clamp_capacity(list_capacity);
-  uint8_t* contrib = nullptr;
-  if ((d->flags & PS_FLAG_CONTRIB_MASKS) && cap > 0) {
-    // (the caller's buffer continues behind the list: ps_raster_point_list_bytes)
-    contrib = (uint8_t*)const_cast<uint32_t*>(point_list) + contrib_offset_bytes(cap);
-    if (hipMemsetAsync(contrib, 0, 2 * (size_t)cap, st) != hipSuccess) return PS_ERR_LAUNCH;
-  }
   Scope sc(G_TILES_FWD, st);
-  launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list, cap, view_params,
-                       out_color, p.final_T, p.n_contrib, p.checkpoint, p.tile_end, contrib, st);
+  launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list,
+                       clamp_capacity(list_capacity), view_params, out_color, p.final_T,
+                       p.n_contrib, p.checkpoint, p.tile_end, st);
   return check_launch();
 }
 
@@ -328,10 +319,7 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
     Scope sc(G_TILES_BWD, st);
     launch_tiles_backward(*d, records, task_order, tile_ranges, point_list, capacity, view_params,
                           final_T, n_contrib, checkpoint, tile_end, dL_dcolor, grad2d, tile_grads,
-                          det_slots,
-                          ((d->flags & PS_FLAG_CONTRIB_MASKS) && capacity > 0)
-                              ? (const uint8_t*)point_list + contrib_offset_bytes(capacity) : nullptr,
-                          st);
+                          det_slots, st);
     if (deterministic)
       launch_deterministic_reduce(*d, radii, rects, (const uint32_t*)(sb + L.sorted_idx),
                                   (const uint32_t*)(sb + L.n_vis), tile_ranges, point_list, capacity,

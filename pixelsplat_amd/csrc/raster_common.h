@@ -145,7 +145,7 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, float4* checkpoint,
-                          uint32_t* tile_end, uint8_t* contrib, hipStream_t st);
+                          uint32_t* tile_end, hipStream_t st);
 
 void launch_backward_task_order(const PsRasterDesc& d, const uint32_t* tile_ranges,
                                 const uint32_t* tile_end, uint32_t capacity, uint32_t* task_order,
@@ -156,13 +156,7 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const float4* checkpoint,
                            const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
-                           float* tile_grads, float* det_slots, const uint8_t* contrib, hipStream_t st);
-// PS_FLAG_CONTRIB_MASKS: the caller's point_list buffer = `capacity` u32 entries, then (16-byte aligned)
-// 2 x capacity mask bytes (one per entry and half tile)
-inline size_t contrib_offset_bytes(size_t capacity) { return align_up(capacity * 4, 16); }
-inline size_t point_list_bytes(const PsRasterDesc& d, size_t capacity) {
-  return (d.flags & PS_FLAG_CONTRIB_MASKS) ? contrib_offset_bytes(capacity) + 2 * capacity : capacity * 4;
-}
+                           float* tile_grads, float* det_slots, hipStream_t st);
 // PS_FLAG_DETERMINISTIC: ranks, then the fixed-order sum of the per-entry slots into grad2d
 void launch_deterministic_reduce(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
                                  const uint32_t* sorted_idx, const uint32_t* n_vis,

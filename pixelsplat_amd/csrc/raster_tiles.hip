@@ -191,12 +191,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //     path: the records of batch i + 1 and the list indices of batch i + 2 are in flight while batch i
 //     is refined and blended.
 constexpr int kFwdMinWaves = 6;      // waves per SIMD the forward's register allocation aims at (80 VGPRs, no spill)
-// CB (PS_FLAG_CONTRIB_MASKS): per list entry the wave leaves the 2-bit mask of ITS quadrants in which at
-// least one pixel took the entry (alpha >= 1/255, not stopped) in contrib[half tile][list position] (one
-// byte per entry and half tile, cleared by the caller).  The backward walks exactly those (entry, quadrant)
-// pairs: the conservative ellipse-vs-box bound it would otherwise recompute keeps ~10 % of quadrants in
-// which no pixel centre reaches 1/255 or every pixel had already stopped.
-template <bool CB>
 __global__ void __launch_bounds__(kWavesPerBlock* kWave, kFwdMinWaves)
 tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ tile_order,
@@ -204,8 +198,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
                      const uint32_t* __restrict__ point_list, uint32_t capacity,
                      const float* __restrict__ view_params, float* __restrict__ out_color,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                     float4* __restrict__ checkpoint, uint32_t* __restrict__ tile_end,
-                     uint8_t* __restrict__ contrib) {
+                     float4* __restrict__ checkpoint, uint32_t* __restrict__ tile_end) {
   constexpr int QW = kFwdQW;          // quadrants (= pixels per lane) of this wave
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int G = d.n_gaussians, H = d.height, W = d.width;
@@ -264,11 +257,8 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
   float Ts[QW];
 #pragma unroll
   for (int k = 0; k < QW; ++k) Ts[k] = live[k] ? 1.f : -1.f;
-  // CB: bit j of cbits[k] = entry j of the current blend call had a contributing pixel in quadrant k
-  // (wave-uniform: the compare masks live in scalar registers anyway)
-  uint64_t cbits[QW];
   // one ring entry against the (up to QW) quadrants of this wave it can reach
-  auto process_entry = [&](const uint32_t j, const float4 q0, const float4 q1, const float4 q2) {
+  auto process_entry = [&](const float4 q0, const float4 q1, const float4 q2) {
     const uint32_t hidx = __float_as_uint(q2.y);
     const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
 #pragma unroll
@@ -289,17 +279,7 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
         C0[k] = fmaf(q1.z, wgt, C0[k]);
         C1[k] = fmaf(q1.w, wgt, C1[k]);
         C2[k] = fmaf(q2.x, wgt, C2[k]);
-        const bool took = ok & !stop;
-        last[k] = took ? hidx : last[k];
-        if (CB) {   // scalar: s_cmp on the compare mask, s_cselect, s_or (the readfirstlanes fold away;
-          // without them the compiler carries the accumulator through the loop in vector registers)
-          // (took <=> wgt > 0: a live pixel's weight T alpha is >= 1e-4 / 255; asked of a plain compare because
-          // the ballot of an AND of two compare masks is lowered through a 0 / 1 select and a second compare)
-          const uint64_t bit = __builtin_amdgcn_ballot_w64(wgt > 0.f) != 0ull ? (1ull << j) : 0ull;
-          const uint64_t nb = cbits[k] | bit;
-          cbits[k] = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) |
-                     (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)nb);
-        }
+        last[k] = (ok & !stop) ? hidx : last[k];
       }
     }
   };
@@ -320,28 +300,15 @@ tiles_forward_kernel(PsRasterDesc d, const float* __restrict__ records,
     const uint32_t bh = __builtin_amdgcn_readfirstlane(b_head);
     uint32_t slot = bh & (kQB - 1);
     float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
-    if (CB) {
-#pragma unroll
-      for (int k = 0; k < QW; ++k) cbits[k] = 0ull;
-    }
     for (uint32_t j = 0; j < m; j += 2) {
       slot = (bh + j + 1) & (kQB - 1);         // (stale beyond m: never processed)
       const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
-      process_entry(j, a0, a1, a2);
+      process_entry(a0, a1, a2);
       if (j + 1 >= m) break;
       slot = (bh + j + 2) & (kQB - 1);
       a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
-      process_entry(j + 1, b0, b1, b2);
+      process_entry(b0, b1, b2);
       if ((j & 7u) == 6u && every_pixel_stopped()) { all_done = true; break; }
-    }
-    if (CB) {      // lane j: the mask of entry j (entries behind an early exit took nothing: 0)
-      if ((uint32_t)lane < m) {
-        const uint32_t hidx = __float_as_uint(lds.rec[(bh + lane) & (kQB - 1)][2].y);
-        uint32_t bits = 0;
-#pragma unroll
-        for (int k = 0; k < QW; ++k) bits |= (uint32_t)((cbits[k] >> lane) & 1ull) << k;
-        contrib[(size_t)(q_first / QW) * capacity + l_start + hidx - 1u] = (uint8_t)bits;
-      }
     }
     b_head = __builtin_amdgcn_readfirstlane(bh + m);
     wave_lds_sync();
@@ -453,19 +420,12 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           const uint32_t* point_list,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, float4* checkpoint,
-                          uint32_t* tile_end, uint8_t* contrib, hipStream_t st) {
+                          uint32_t* tile_end, hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = m.V * m.tiles * kFwdParts;
   dim3 grid((total + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * kWave);
-  static_assert(kFwdParts == 2, "one mask byte per list entry and HALF tile");
-  if (contrib != nullptr)
-    hipLaunchKernelGGL(tiles_forward_kernel<true>, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                       point_list, capacity, view_params, out_color, final_T, n_contrib, checkpoint, tile_end,
-                       contrib);
-  else
-    hipLaunchKernelGGL(tiles_forward_kernel<false>, grid, block, 0, st, d, records, tile_order, tile_ranges,
-                       point_list, capacity, view_params, out_color, final_T, n_contrib, checkpoint, tile_end,
-                       (uint8_t*)nullptr);
+  hipLaunchKernelGGL(tiles_forward_kernel, grid, block, 0, st, d, records, tile_order, tile_ranges,
+                     point_list, capacity, view_params, out_color, final_T, n_contrib, checkpoint, tile_end);
 }
 
 // ------------------------------------------------------------------------------------
@@ -519,11 +479,7 @@ __device__ __forceinline__ void wave_sum9_partials(float a, float b, float c, fl
 // slower (2.17 ms).
 // DET (PS_FLAG_DETERMINISTIC): the partial gradient of a Gaussian over more than kInvSlots tiles goes to the
 // slot of its list entry (det_slots[list position], cleared by the caller) instead of nine float atomics.
-// CB (PS_FLAG_CONTRIB_MASKS): the quadrants of an entry are the ones the FORWARD found a contributing pixel
-// in (contrib[half][list position]) instead of the conservative ellipse-vs-box bound: the same pixels
-// contribute either way (results bitwise equal), the ~10 % of quadrant evaluations that end in all-zero
-// updates and the bound's arithmetic are not executed.
-template <bool DET, bool CB>
+template <bool DET>
 __global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, 4)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const uint32_t* __restrict__ task_order,
@@ -534,7 +490,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
                       const float4* __restrict__ checkpoint,
                       const uint32_t* __restrict__ tile_end, const float* __restrict__ dL_dcolor,
                       float* __restrict__ grad2d, float* __restrict__ tile_grads,
-                      float4* __restrict__ det_slots, const uint8_t* __restrict__ contrib) {
+                      float4* __restrict__ det_slots) {
   __shared__ WaveLdsBwd lds_all[kWavesPerBlockBwd];
   const int G = d.n_gaussians, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
@@ -649,17 +605,12 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     float4 q0, q1, q2;
     const uint32_t id_now = id_ahead;
     if (top - m > lo) id_ahead = idx_of(top - m);
-    uint32_t cmask = 0;
-    if (CB) {      // (loads outside the condition: issued with the record gather, not after it)
-      const size_t e = (size_t)l_start + ((uint32_t)lane < m ? top - 1u - (uint32_t)lane : top - 1u);
-      cmask = (uint32_t)(contrib[e] & 3u) | ((uint32_t)(contrib[(size_t)capacity + e] & 3u) << 2);
-    }
     if ((uint32_t)lane < m) {
       const uint32_t id = id_now;
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
       const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
-      const uint32_t qm = CB ? cmask : quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
+      const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
       keep = qm != 0u;
       q0 = make_float4(r0.x, r0.y, A, B);
       q1 = make_float4(Cq, r1.y, r2.x, r2.y);
@@ -960,17 +911,18 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            uint32_t capacity, const float* view_params, const float* final_T,
                            const uint32_t* n_contrib, const float4* checkpoint,
                            const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
-                           float* tile_grads, float* det_slots, const uint8_t* contrib, hipStream_t st) {
+                           float* tile_grads, float* det_slots, hipStream_t st) {
   const Dims m = make_dims(d);
   const int total = 2 * m.V * m.tiles;
   dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
-#define PS_BWD(DET, CB)                                                                                   \
-  hipLaunchKernelGGL((tiles_backward_kernel<DET, CB>), grid, block, 0, st, d, records, task_order,        \
-                     tile_ranges, point_list, capacity, view_params, final_T, n_contrib, checkpoint,      \
-                     tile_end, dL_dcolor, grad2d, tile_grads, reinterpret_cast<float4*>(det_slots), contrib)
-  if (det_slots != nullptr) { if (contrib) PS_BWD(true, true); else PS_BWD(true, false); }
-  else { if (contrib) PS_BWD(false, true); else PS_BWD(false, false); }
-#undef PS_BWD
+  if (det_slots != nullptr)
+    hipLaunchKernelGGL(tiles_backward_kernel<true>, grid, block, 0, st, d, records, task_order, tile_ranges,
+                       point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
+                       dL_dcolor, grad2d, tile_grads, reinterpret_cast<float4*>(det_slots));
+  else
+    hipLaunchKernelGGL(tiles_backward_kernel<false>, grid, block, 0, st, d, records, task_order, tile_ranges,
+                       point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
+                       dL_dcolor, grad2d, tile_grads, (float4*)nullptr);
 }
 
 }  // namespace ps

@@ -62,10 +62,6 @@ class RasterConfig:
     # atomics (PS_FLAG_DETERMINISTIC: two runs are bitwise equal; more scratch, slower -- for parity and
     # reproducibility runs).  None: the PIXELSPLAT_DETERMINISTIC environment variable decides (default off)
     deterministic: bool | None = None
-    # the tile forward leaves, per list entry, the quadrants a pixel took it in; the tile backward walks
-    # exactly those (PS_FLAG_CONTRIB_MASKS; results bitwise equal, ~10 % fewer quadrant evaluations).
-    # None: on unless PIXELSPLAT_CONTRIB_MASKS=0 (A/B runs)
-    contrib_masks: bool | None = None
 
     def desc(self) -> _lib.PsRasterDesc:
         d = _lib.default_desc()
@@ -80,12 +76,6 @@ class RasterConfig:
             det = os.environ.get("PIXELSPLAT_DETERMINISTIC", "0") not in ("", "0")
         if det:
             d.flags |= _lib.PS_FLAG_DETERMINISTIC
-        cm = self.contrib_masks
-        if cm is None:
-            import os
-            cm = os.environ.get("PIXELSPLAT_CONTRIB_MASKS", "1") not in ("", "0")
-        if cm:
-            d.flags |= _lib.PS_FLAG_CONTRIB_MASKS
         return d
 
     @property
@@ -140,14 +130,6 @@ class ForwardResult:
                 f"(exact sizing)")
 
 
-def _alloc_point_list(lib, d, entries: int, dev) -> Tensor:
-    """int32 [entries]: the tile point list -- a view of a buffer that also holds what the library keeps
-    behind it (PS_FLAG_CONTRIB_MASKS: 2 mask bytes per entry; ps_raster_point_list_bytes)."""
-    nbytes = lib.ps_raster_point_list_bytes(C.byref(d), entries)
-    buf = torch.empty(((nbytes + 3) // 4,), dtype=torch.int32, device=dev)
-    return buf[:entries]
-
-
 def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params) -> ForwardResult:
     lib = _lib.load()
     d = cfg.desc()
@@ -157,7 +139,7 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params) ->
     state = torch.empty(lib.ps_raster_state_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
     temp = torch.empty(lib.ps_raster_temp_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
     if cfg.list_capacity > 0:
-        plist = _alloc_point_list(lib, d, cfg.list_capacity, dev)
+        plist = torch.empty(cfg.list_capacity, dtype=torch.int32, device=dev)
         _lib.check(lib.ps_raster_forward_plan(
             C.byref(d), _p(means), _p(cov), _p(sh), _p(colors), _p(opacity), _p(view_params),
             _p(radii), _p(state), state.numel(), _p(temp), temp.numel(), _stream()),
@@ -203,15 +185,13 @@ def _forward(cfg: RasterConfig, means, cov, opacity, sh, colors, view_params) ->
             _p(temp), temp.numel(), _stream()), "ps_raster_forward_colors")
     copied.synchronize()
     n = C.c_uint64(int(host[0]) & 0xFFFFFFFF)
-    # (the SAME capacity goes to the forward and, through plist.numel(), to the backward: the masks behind
-    # the list are addressed by it)
-    plist = _alloc_point_list(lib, d, max(int(n.value), 1), dev)
+    plist = torch.empty(max(int(n.value), 1), dtype=torch.int32, device=dev)
     _lib.check(lib.ps_raster_forward_bins(
-        C.byref(d), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist), plist.numel(),
+        C.byref(d), _p(state), state.numel(), _p(temp), temp.numel(), _p(plist), int(n.value),
         _stream()), "ps_raster_forward_bins")
     _lib.check(lib.ps_raster_forward_tiles(
         C.byref(d), _p(view_params), _p(color), _p(state), state.numel(), _p(temp), temp.numel(),
-        _p(plist), plist.numel(), _stream()), "ps_raster_forward_tiles")
+        _p(plist), int(n.value), _stream()), "ps_raster_forward_tiles")
     return ForwardResult(color, radii, state, plist, int(n.value))
 
 

@@ -336,19 +336,9 @@ def test_one_call_abi_equals_the_split_calls(gpu_device):
     for ga, gb in zip(grads_a, grads_b):
         torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-7)   # atomics for large Gaussians
 
-    # the single-call ABI, as a host that knows nothing of PS_FLAG_CONTRIB_MASKS calls it: flags = 0, the
-    # point list is list_capacity u32 entries and nothing more (the backward then derives the quadrant masks
-    # from its conservative bound: same pixels contribute, same gradients)
+    # the single-call ABI
     lib = _lib.load()
-    plain = dataclasses.replace(cfg, contrib_masks=False)
-    d = plain.desc()
-    assert not (d.flags & _lib.PS_FLAG_CONTRIB_MASKS) and (cfg.desc().flags & _lib.PS_FLAG_CONTRIB_MASKS)
-    assert lib.ps_raster_point_list_bytes(C.byref(d), 200000) == 800000
-    assert lib.ps_raster_point_list_bytes(C.byref(cfg.desc()), 200000) == 800000 + 2 * 200000
-    img_c, _, grads_c = run(plain)
-    assert torch.equal(img_c, img_a)
-    for ga, gc in zip(grads_a, grads_c):
-        torch.testing.assert_close(ga, gc, rtol=1e-5, atol=1e-7)
+    d = cfg.desc()
     color = torch.empty((V, 3, 64, 64), dtype=torch.float32, device=dev)
     radii = torch.empty((V, means.shape[1]), dtype=torch.int32, device=dev)
     state = torch.empty(lib.ps_raster_state_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
@@ -373,7 +363,7 @@ def test_one_call_abi_equals_the_split_calls(gpu_device):
     dL = torch.linspace(0.5, 1.5, img_a.numel(), device=dev).view_as(img_a).contiguous()
 
     def raw_backward(prepare):
-        db = plain.desc()
+        db = cfg.desc()
         tb = torch.empty(lib.ps_raster_backward_temp_bytes(C.byref(db), plist.numel()), dtype=torch.uint8,
                          device=dev)
         tb.view(torch.float32)[: tb.numel() // 4].fill_(float("nan"))
