@@ -95,6 +95,56 @@ def test_depth_span_over_27_bits_takes_the_fourth_sort_pass(gpu_device):
         _grad_close(g["opacity"], ref["opacity"], "opacity")
 
 
+def test_one_launch_mixing_three_and_four_pass_views(gpu_device):
+    """the fourth radix pass is decided PER VIEW on the device (its kernels return at once for a
+    3-pass view) and a view's last pass redirects its output to sorted_idx -- the value buffers ping-pong
+    differently for the two kinds of view.  One launch with views 3-pass | 4-pass | 3-pass | 4-pass: every
+    view's radii, tile counts and sorted tile lists bit-exact against the oracle, image and gradients at the
+    usual bars."""
+    from pixelsplat_amd.raster import (RasterConfig, export_bins, forward_with_state, pack_view_params,
+                                       rasterize)
+
+    dev = gpu_device
+    hw, n = (48, 64), 600
+    scs = []
+    for i, far_scale in enumerate((1.0, 1e5, 1.0, 3e4)):
+        sc = small_scene(n, hw, seed=30 + i, dtype=np.float32)
+        rng = np.random.default_rng(40 + i)
+        far = rng.random(n) < 0.33
+        f = np.where(far, far_scale * rng.uniform(0.25, 1.0, n), 1.0).astype(np.float32)
+        sc["means"] = (sc["means"] * f[:, None]).astype(np.float32)
+        sc["cov6"] = (sc["cov6"] * (f * f)[:, None]).astype(np.float32)
+        span = int(np.float32(sc["means"][:, 2].max()).view(np.uint32)) - int(np.float32(0.2).view(np.uint32))
+        assert (span >= 1 << 27) == (far_scale > 1.0)
+        scs.append(sc)
+    V = len(scs)
+    stack = lambda k: torch.from_numpy(np.stack([sc[k] for sc in scs])).to(dev)
+    means, cov6, sh = stack("means").requires_grad_(True), stack("cov6"), stack("sh")
+    op = stack("opacity").requires_grad_(True)
+    vp = pack_view_params(stack("view").reshape(V, 4, 4), stack("proj").reshape(V, 4, 4), stack("campos"),
+                          torch.tensor([[sc["tanfovx"], sc["tanfovy"]] for sc in scs], device=dev), stack("bg"))
+    cfg = RasterConfig(n_scenes=V, views_per_scene=1, n_gaussians=n, height=hw[0], width=hw[1], sh_degree=4,
+                       sh_coeffs=25)
+    img, radii = rasterize(cfg, means, cov6, op, vp, sh=sh)
+    dL = np.random.default_rng(9).normal(size=(V, 3) + hw).astype(np.float32)
+    (img * torch.from_numpy(dL).to(dev)).sum().backward()
+    res, lay = forward_with_state(cfg, means.detach(), cov6, op.detach(), vp, sh=sh)
+    counts, offsets, plist = export_bins(cfg, res.state, lay, res.point_list)
+    counts, offsets, plist = counts.cpu().numpy(), offsets.cpu().numpy(), plist.cpu().numpy()
+    for v, sc in enumerate(scs):
+        st = R.forward(dtype=np.float32, **sc)
+        assert np.array_equal(radii[v].cpu().numpy(), st.radii), v
+        assert int((st.radii > 0).sum()) > 300
+        cnt = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
+        assert np.array_equal(counts[v], cnt), v
+        o0 = int(offsets[v, 0])
+        assert np.array_equal(plist[o0:o0 + st.num_rendered], st.point_list), f"sorted tile lists of view {v}"
+        assert np.abs(img[v].detach().cpu().numpy() - st.image).max() < IMG_TOL, v
+        ref = R.backward(st, dL[v])
+        _grad_close(means.grad[v].cpu().numpy(), ref["means3D"], f"means3D of view {v}")
+        _grad_close(op.grad[v].cpu().numpy(), ref["opacity"], f"opacity of view {v}")
+
+
 def test_colors_precomp_path(gpu_device):
     sc = small_scene(300, (48, 64), seed=11, dtype=np.float32, sh_degree=0)
     sc["colors"] = np.random.default_rng(1).uniform(0, 1, (300, 3)).astype(np.float32)
