@@ -1041,6 +1041,14 @@ def main():
             cb["sample"] += (f"; (A) oracle/epipolar_ref.py (unfused, torch CPU autograd) on 1 of "
                              f"{b} scenes, fwd+bwd, {t_a:.1f} s; value = {V} views / "
                              f"({b} x scene time + {V} x view time)")
+            # the REFERENCE's own path-(A) code on a CPU (SURVEY.md 8d / BASELINE.md 4.2): it cannot run on
+            # this box (no /root/reference here); tools/time_reference_cpu.py measured it in the build
+            # container and the committed record travels with the line, labelled with its host
+            try:
+                with open(os.path.join(ROOT, "profiles", "r5_reference_cpu_container.json")) as f:
+                    cb["reference_in_build_container"] = json.load(f)
+            except OSError:
+                cb["reference_in_build_container"] = None
             out["cpu_baseline"] = cb
             out["parity_vs_oracle"] = parity
         json_out.write(json.dumps(out) + "\n")
