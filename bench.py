@@ -153,6 +153,18 @@ def pmc_valu_busy_ms(group):
     return tot or None
 
 
+def pmc_sq_counter(group, counter):
+    """Sum of one SQ counter over the kernel(s) behind a profile group, per launch, from the committed PMC
+    summary of the same workload and the same code (None otherwise)."""
+    keys, path = SINGLE_KERNEL_GROUPS.get(group), _pmc_file("sq", group)
+    if keys is None or path is None:
+        return None
+    with open(path) as f:
+        kernels = json.load(f)["kernels"]
+    tot = sum(float(v.get(counter, 0.0)) for name, v in kernels.items() if any(k in name for k in keys))
+    return tot or None
+
+
 def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu, dL, grad_fn):
     """The oracle (CPU port of the same algorithm) timed on the host cores over a bounded
     sample of the same workload: the first `n_views` views of the batch (scene-major; default:
@@ -174,7 +186,7 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu, dL, grad_fn):
     linf_all, linf_ok, linf_T, mse, n_over, n_marked, n_pix = 0.0, 0.0, 0.0, [], 0, 0, 0
     nc_mismatch = bins_mismatch = radii_mismatch = 0
     explain = dict(same=0, flipped=0, unexplained=0, exhausted=0)
-    pairs_eval = pairs_contrib = 0
+    pairs_eval = pairs_contrib = quad_entries = quad_pairs = 0
     vps = tgt.near.shape[1]
     G = gaussians.means.shape[1]
     n_scenes = (n_views + vps - 1) // vps
@@ -191,6 +203,9 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu, dL, grad_fn):
         ev_, co_ = R.blend_stats(st)
         pairs_eval += ev_
         pairs_contrib += co_
+        qe_, qp_ = R.quadrant_evaluations(st)      # what the tile kernels' 8x8 quadrant cull evaluates
+        quad_entries += qe_
+        quad_pairs += qp_
         img = gpu["images"][v]
         radii_mismatch += int((gpu["radii"][v] != st.radii).sum())
         cnt = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
@@ -243,7 +258,7 @@ def cpu_baseline(gaussians, tgt, vps_np, hw, n_views, gpu, dL, grad_fn):
                        f"{hw[0]}x{hw[1]}, G={gaussians.means.shape[1]}, fwd+bwd, "
                        f"oracle/raster_ref.c with OpenMP on {cores} threads, {t_total:.1f} s"), \
         dict(views=n_views, pairs_evaluated_by_reference=pairs_eval,
-             pairs_contributing=pairs_contrib), \
+             pairs_contributing=pairs_contrib, quadrant_entries=quad_entries, quadrant_pairs=quad_pairs), \
         dict(views_compared=n_views, launch="the benchmarked one: all scenes of the batch in one call",
              linf=linf_ok, linf_final_T=linf_T, psnr_db=psnr if psnr != float("inf") else 999.0,
              pixels_compared=n_pix, pixels_over_1e_4=n_over, pixels_on_a_threshold=n_marked,
@@ -832,6 +847,19 @@ def main():
             "epipolar_attention_backward": fm + RA * (12.0 * TA + 4.0 * heads * (2 * d_feat + 2 * PA + 2 * TA)),
             "epipolar_feature_grad": fm + RA * (8.0 * TA + 4.0 * heads * (2 * d_feat + 2 * TA)),
         })
+        # the two-pass feature gradient writes and re-reads the token-gradient tensor: its floor
+        alg["epipolar_feature_grad"] = fm + 2 * 4.0 * float(RA) * TA * d_feat
+        dom = max((k for k in alg if k in groups), key=lambda k: groups[k][0])
+        dom_ms = groups[dom][0]
+        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+        # committed PMC summaries exist for the three benchmarked BASELINE configurations
+        global PMC_TAG
+        PMC_TAG = {(256, 256, 7, 4, 2): "c2", (256, 256, 4, 4, 3): "c4",
+                   (512, 512, 2, 4, 2): "c5"}.get((hw[0], hw[1], b, v, vc))
+        if args.scene != "survey":      # counters are taken on the BASELINE (survey) workload only
+            PMC_TAG = None
+        is_c2 = PMC_TAG is not None
+        traffic, traffic_src = pmc_traffic(dom)
         # (A) against the fp32 vector peak: FOLDED useful flops = what the fused
         # kernels have to compute per launch (score + context: 2 x (c + P) MACs per (ray, token, head);
         # bilinear interpolation 4 corners x c MACs per token; token gradient 2 c MACs per (token, layer,
@@ -848,8 +876,6 @@ def main():
             # one launch group per step, both layers at once
             "epipolar_feature_grad": (tok * n_layers_a * heads * 2 * d_feat * 2 + tok * 4 * d_feat * 2, 0.0),
         }
-        # the two-pass feature gradient writes and re-reads the token-gradient tensor: its floor
-        alg["epipolar_feature_grad"] = fm + 2 * 4.0 * tok * d_feat
         roofline_a = {}
         for k_, (ff, rf) in flops_a.items():
             if k_ in groups and groups[k_][0] > 0:
@@ -871,17 +897,6 @@ def main():
             roofline_a["gemm_tn_splitk"] = {
                 "ms": round(ms_, 4), "gflop": round(ff / 1e9, 2), "tflops": round(ff / (ms_ * 1e-3) / 1e12, 1),
                 "bound": "mfma", "peak": VEC_PEAK, "frac_of_fp32_matrix_peak": round(ff / (ms_ * 1e-3) / 1e12 / VEC_PEAK, 4)}
-        dom = max((k for k in alg if k in groups), key=lambda k: groups[k][0])
-        dom_ms = groups[dom][0]
-        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
-        # committed PMC summaries exist for the three benchmarked BASELINE configurations
-        global PMC_TAG
-        PMC_TAG = {(256, 256, 7, 4, 2): "c2", (256, 256, 4, 4, 3): "c4",
-                   (512, 512, 2, 4, 2): "c5"}.get((hw[0], hw[1], b, v, vc))
-        if args.scene != "survey":      # counters are taken on the BASELINE (survey) workload only
-            PMC_TAG = None
-        is_c2 = PMC_TAG is not None
-        traffic, traffic_src = pmc_traffic(dom)
         valu_ms = pmc_valu_busy_ms(dom) if is_c2 else None
         out = {
             "metric": "rendered views/sec (fwd+bwd)", "value": round(value, 2), "unit": "views/s",
@@ -1032,7 +1047,19 @@ def main():
                     "pairs_evaluated_by_reference_per_step": int(work["pairs_evaluated_by_reference"] * scale_v),
                     "avg_kernel_ms": round(t_ms, 4),
                     "valu_issue_frac": (round(pmc_valu_busy_ms(kname) / t_ms, 3)
-                                        if pmc_valu_busy_ms(kname) else None)}
+                                        if pmc_valu_busy_ms(kname) else None),
+                    # what a lane does: the (entry, 8x8 quadrant) pairs the kernels'
+                    # conservative cull evaluates up to every tile's last contributor (oracle walk, numpy
+                    # restatement of quadrant_mask), 64 lanes each, against the pairs that contribute; and
+                    # the VALU instructions the kernel really issued (committed SQ_INSTS_VALU of this build)
+                    "quadrant_evaluations_per_step": int(work["quadrant_pairs"] * scale_v),
+                    "list_entries_reaching_a_quadrant_per_step": int(work["quadrant_entries"] * scale_v),
+                    "lane_efficiency": round(contrib / max(work["quadrant_pairs"] * scale_v * 64.0, 1.0), 4),
+                    "valu_wave_instructions_per_launch": (int(pmc_sq_counter(kname, "SQ_INSTS_VALU"))
+                                                          if pmc_sq_counter(kname, "SQ_INSTS_VALU") else None),
+                    "valu_lane_instructions_per_contributing_pair": (
+                        round(pmc_sq_counter(kname, "SQ_INSTS_VALU") * 64.0 / contrib, 1)
+                        if pmc_sq_counter(kname, "SQ_INSTS_VALU") else None)}
             t_a = cpu_baseline_epipolar(et, feat, ctx, n_samp, heads, view_shuffle)   # one scene
             t_step = b * t_a + V / cb["value"]
             cb["raster_only_views_per_s"] = round(cb["value"], 3)

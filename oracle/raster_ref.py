@@ -231,6 +231,52 @@ def blend_stats(st: ForwardState) -> tuple[int, int]:
     return int(out[0]), int(out[1])
 
 
+def quadrant_evaluations(st: ForwardState, alpha_min: float = 1.0 / 255.0) -> tuple[int, int]:
+    """(list entries that reach at least one 8x8 quadrant of their tile, (entry, quadrant) pairs) under the
+    product's conservative ellipse-vs-box bound (csrc/raster_tiles.hip quadrant_mask, restated in numpy): what
+    the tile kernels evaluate -- 64 lanes per pair -- before the last contributor / early termination cut the
+    walk.  A statistic for bench.py's `lane_efficiency` (contributing pairs / (pairs x 64)); not a parity path."""
+    n = st.num_rendered
+    if n == 0:
+        return 0, 0
+    gx = (st.params.W + 15) // 16
+    cnt = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
+    tile = np.repeat(np.arange(cnt.size), cnt)
+    # only the part of every list up to the tile's last contributor is walked
+    nc = st.n_contrib.reshape(st.params.H, st.params.W)
+    hp, wp = -(-st.params.H // 16) * 16, gx * 16
+    pad = np.zeros((hp, wp), nc.dtype)
+    pad[:st.params.H, :st.params.W] = nc
+    last = pad.reshape(hp // 16, 16, gx, 16).max(axis=(1, 3)).reshape(-1)
+    pos = np.arange(n) - np.repeat(st.ranges[:, 0].astype(np.int64), cnt)
+    walked = pos < last[tile]
+    ids = st.point_list.astype(np.int64)[walked]
+    tile = tile[walked]
+    x0 = (tile % gx * 16).astype(np.float32)
+    y0 = (tile // gx * 16).astype(np.float32)
+    px, py = st.xy[ids, 0].astype(np.float32), st.xy[ids, 1].astype(np.float32)
+    co = st.conic_opacity[ids].astype(np.float32)
+    k = np.float32(1.4426950408889634)
+    A, B, Cq, op = -0.5 * k * co[:, 0], -k * co[:, 1], -0.5 * k * co[:, 2], co[:, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tau = np.log2(op / np.float32(alpha_min))
+        pd = (A < 0) & (Cq < 0) & (4 * A * Cq - B * B > 0)
+        pairs = np.zeros(ids.size, np.int64)
+        for q in range(4):
+            bx, by = x0 + 8 * (q & 1), y0 + 8 * (q >> 1)
+            dxlo, dxhi, dylo, dyhi = px - (bx + 7), px - bx, py - (by + 7), py - by
+            ex = np.where(dxlo > 0, dxlo, np.where(dxhi < 0, dxhi, 0))
+            ey = np.where(dylo > 0, dylo, np.where(dyhi < 0, dyhi, 0))
+            qmin = np.full(ids.size, 3.0e38, np.float32)
+            dy = np.minimum(dyhi, np.maximum(dylo, -B * ex / (2 * Cq)))
+            qmin = np.where(ex != 0, np.minimum(qmin, -(A * ex * ex + B * ex * dy + Cq * dy * dy)), qmin)
+            dx = np.minimum(dxhi, np.maximum(dxlo, -B * ey / (2 * A)))
+            qmin = np.where(ey != 0, np.minimum(qmin, -(A * dx * dx + B * dx * ey + Cq * ey * ey)), qmin)
+            may = ((ex == 0) & (ey == 0)) | ~(qmin > tau + 1e-4 * np.abs(tau) + 1e-3)
+            pairs += (tau >= 0) & (~pd | may)
+    return int((pairs > 0).sum()), int(pairs.sum())
+
+
 def backward(st: ForwardState, dL_dimage):
     """Returns dict(means3D, means2D, cov6, sh|colors, opacity) -- the five gradients the
     reference's autograd needs (SURVEY.md section 8b 'Gradients required')."""

@@ -102,3 +102,30 @@ def test_kernel_table_reads_the_committed_summaries():
     assert any(r.startswith("ps::tiles_backward_kernel") for r in rows) and len(rows) > 20
     first = [r for r in rows if r.startswith("ps::tiles_backward_kernel")][0].split()
     assert float(first[2]) > 100.0 and float(first[3]) > 0.5      # avg us, traffic GB of the dominant kernel
+
+
+def test_committed_gpu_test_log_is_of_this_build():
+    """the committed GPU-suite log (profiles/r5_gpu_tests.log, written by
+    tools/profile_all_configs.sh on the GPU box) starts with the `ps_build_info()` of the library that ran it.
+    Every translation unit's hash in that stamp must equal the hash of the sources in the tree (a kernel change
+    after the last full GPU suite -- round 4's failure -- turns this test red here, on the CPU), and the log must
+    end in at least 125 passed tests and no failure."""
+    import re
+
+    from pixelsplat_amd import build
+
+    path = os.path.join(ROOT, "profiles", "r5_gpu_tests.log")
+    assert os.path.exists(path), "no committed GPU-suite log: run tools/profile_all_configs.sh r5 tests on the GPU box"
+    text = open(path).read()
+    first = text.splitlines()[0]
+    assert first.startswith("build:"), first[:80]
+    stamped = dict(tok.split(":", 1) for tok in first.split("|", 1)[-1].split() if ":" in tok)
+    units = build.SOURCES + [(f, []) for f in sorted(os.listdir(build.CSRC))
+                             if f.endswith(".hip") and f not in {s_ for s_, _ in build.SOURCES}]
+    want = dict(tok.split(":") for tok in build.unit_hashes([u for u in units if u[0] != "raster_api.hip"]).split())
+    assert set(want) <= set(stamped), sorted(set(want) - set(stamped))
+    stale = {u: (stamped[u], h) for u, h in want.items() if stamped[u] != h}
+    assert not stale, f"the GPU suite was last run on other code than the tree holds: {stale}"
+    tail = text.strip().splitlines()[-1]
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 125 and "failed" not in tail and "error" not in tail.lower(), tail
