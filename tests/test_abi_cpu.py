@@ -50,6 +50,25 @@ def test_desc_defaults_and_sizes(lib):
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
 
 
+def test_abi_version_and_optional_flags(lib):
+    """Round 5: the library reports the layout version of its descriptor structs (PsEpipolarDesc
+    grew without a guard) and the header, the loader and the library agree on it; PS_FLAG_DETERMINISTIC is
+    accounted for in the backward scratch size (48 B per list entry + 4 B per (view, Gaussian))."""
+    from pixelsplat_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "pixelsplat_hip.h")).read()
+    ver = int(re.search(r"#define\s+PS_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.ps_abi_version() == ver == _lib.PS_ABI_VERSION
+    assert int(re.search(r"#define\s+PS_FLAG_DETERMINISTIC\s+(\d+)", hdr).group(1)) == _lib.PS_FLAG_DETERMINISTIC
+    d = _lib.default_desc()
+    d.n_scenes, d.views_per_scene, d.n_gaussians, d.height, d.width = 1, 4, 393216, 256, 256
+    d.sh_degree, d.sh_coeffs = 4, 25
+    cap = 2_000_000
+    plain = lib.ps_raster_backward_temp_bytes(C.byref(d), cap)
+    d.flags |= _lib.PS_FLAG_DETERMINISTIC
+    det = lib.ps_raster_backward_temp_bytes(C.byref(d), cap)
+    assert det >= plain + cap * 48 + 4 * 393216 * 4 and det < plain + cap * 48 + 4 * 393216 * 4 + 4096
+
+
 def test_bad_arguments_are_status_codes_not_crashes(lib):
     from pixelsplat_amd import _lib
     d = _lib.default_desc()
