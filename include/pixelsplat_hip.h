@@ -206,7 +206,9 @@ int ps_raster_check(const PsRasterDesc* desc, const void* state, size_t state_by
 /* Zeroes the backward temp buffer's accumulators (all of them).  Optional since round 3 --
  * ps_raster_backward clears what it needs itself (see PS_FLAG_BWD_TEMP_ZEROED).  Issue it any time
  * after list_capacity is known and before ps_raster_backward, on any stream; then set
- * PS_FLAG_BWD_TEMP_ZEROED in the descriptor handed to ps_raster_backward. */
+ * PS_FLAG_BWD_TEMP_ZEROED in the descriptor handed to ps_raster_backward.   Not for use inside a stream capture: it is the one entry point that issues a
+ * hipMemsetAsync, and a memset node replayed from a hipGraph did not clear what the eager call clears on
+ * ROCm 7.2 (round 5: PS_FLAG_DETERMINISTIC cleared its slots that way at first; it uses a kernel now). */
 int ps_raster_backward_prepare(const PsRasterDesc* desc, void* temp, size_t temp_bytes,
                                size_t list_capacity, void* stream);
 

@@ -302,9 +302,7 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
     // only the grad2d rows the tile backward adds into with atomics (pairs over > kInvSlots
     // tiles); the private slots are written exactly once each and need no clearing
     if (deterministic) {      // no atomics: the per-entry slots start from zero instead
-      if (capacity > 0 &&
-          hipMemsetAsync(det_slots, 0, (size_t)capacity * kSlotFloats * 4, st) != hipSuccess)
-        return PS_ERR_LAUNCH;
+      launch_deterministic_clear(det_slots, capacity, st);
     } else if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
       launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
     }

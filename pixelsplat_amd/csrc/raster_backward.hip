@@ -421,6 +421,23 @@ det_reduce_kernel(size_t n, int G, int gx, int gy, const int32_t* __restrict__ r
   for (int c = 0; c < kGradFloats; ++c) g[c] = acc[c];
 }
 
+// the per-entry slots start from zero (a kernel, not hipMemsetAsync: the one memset node this library would
+// put into a captured step gave wrong gradients when the step was replayed from a hipGraph -- bench.py's
+// step_check caught it, round 5 -- while every kernel launch replays correctly)
+__global__ void __launch_bounds__(256)
+det_clear_kernel(size_t n4, float4* __restrict__ p) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_deterministic_clear(float* det_slots, size_t entries, hipStream_t st) {
+  const size_t n4 = entries * (kSlotFloats / 4);
+  if (n4 == 0) return;
+  const size_t blocks = (n4 + 255) / 256;
+  hipLaunchKernelGGL(det_clear_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, n4,
+                     reinterpret_cast<float4*>(det_slots));
+}
+
 void launch_deterministic_reduce(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
                                  const uint32_t* sorted_idx, const uint32_t* n_vis,
                                  const uint32_t* tile_ranges, const uint32_t* point_list,

@@ -157,6 +157,7 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
                            const uint32_t* n_contrib, const float4* checkpoint,
                            const uint32_t* tile_end, const float* dL_dcolor, float* grad2d,
                            float* tile_grads, float* det_slots, hipStream_t st);
+void launch_deterministic_clear(float* det_slots, size_t entries, hipStream_t st);
 // PS_FLAG_DETERMINISTIC: ranks, then the fixed-order sum of the per-entry slots into grad2d
 void launch_deterministic_reduce(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
                                  const uint32_t* sorted_idx, const uint32_t* n_vis,

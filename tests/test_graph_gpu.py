@@ -20,7 +20,11 @@ def _scene(dev, hw=(64, 64), v=3, seed=5):
     return leaves, cams, target.reshape(v, 3, *hw).to(dev)
 
 
-def test_rasterizer_step_replayed_from_a_graph_equals_eager(gpu_device):
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_rasterizer_step_replayed_from_a_graph_equals_eager(gpu_device, deterministic):
+    """`deterministic=True` (PS_FLAG_DETERMINISTIC): the replayed gradients must equal the eager ones BIT FOR BIT
+    -- round 5's first form of the mode cleared its slots with hipMemsetAsync, the only memset node of a captured
+    step, and gave garbage gradients when replayed (bench.py's step_check caught it; a kernel clears them now)."""
     from pixelsplat_amd.decoder import render_cuda
     from pixelsplat_amd.loss import mse_loss
     from pixelsplat_amd.raster import captured_overflow_flags
@@ -33,7 +37,8 @@ def test_rasterizer_step_replayed_from_a_graph_equals_eager(gpu_device):
     def step(cap):
         for t in leaves:
             t.grad = None
-        img = render_cuda(*cams, hw, bg, *leaves, views_per_scene=v, list_capacity=cap)
+        img = render_cuda(*cams, hw, bg, *leaves, views_per_scene=v, list_capacity=cap,
+                          deterministic=deterministic)
         mse_loss(img, target, 1.0).backward()
         return img.detach()
 
@@ -58,7 +63,10 @@ def test_rasterizer_step_replayed_from_a_graph_equals_eager(gpu_device):
     assert flags and not flags[-1][1] and 0 < flags[-1][0] <= cap
     assert torch.equal(img_static, img_eager)
     for t, ref in zip(leaves, grads_eager):
-        torch.testing.assert_close(t.grad, ref, rtol=1e-5, atol=1e-8)
+        if deterministic:
+            assert torch.equal(t.grad, ref)
+        else:
+            torch.testing.assert_close(t.grad, ref, rtol=1e-5, atol=1e-8)
 
     # a list that does not fit: the replay completes, the flag says so afterwards
     for t in leaves:
