@@ -64,7 +64,7 @@ def test_oracle_chain_reproduces_the_reference_chain():
                                           sh[0].permute(0, 2, 1).contiguous(), dict(H=h, W=w, **keep)))
     img = torch.stack(images)[None]
     err = (img.detach() - t("image")).abs()
-    assert float(err.quantile(0.999)) < 1e-4 and float(err.max()) < 5e-3, (float(err.quantile(0.999)), float(err.max()))
+    assert float(err.max()) < 1e-6, float(err.max())        # measured: 0.0 (same rasterizer, same glue, same Gaussians)
     loss = ((img - t("target")) ** 2).mean()          # loss_mse.py:30-31, weight 1
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
     loss.backward()
@@ -73,4 +73,4 @@ def test_oracle_chain_reproduces_the_reference_chain():
     l2 = float((x - y).norm() / y.norm())
     print(f"\noracle chain vs reference chain: image p99.9 {float(err.quantile(0.999)):.1e} max {float(err.max()):.1e}, "
           f"d(transformer output): 1 - cos {1 - cos:.1e}, relative L2 {l2:.1e}")
-    assert cos > 0.9999 and l2 < 1e-2, (cos, l2)
+    assert cos > 1 - 1e-9 and l2 < 1e-5, (cos, l2)          # measured: 1 - cos 3e-14, relative L2 1.3e-7
