@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(256) seq(float* out, uint64_t* ticks, int iter
   float c0 = 0.5f, c1 = 0.25f, c2 = 0.125f;
   const float amax = 0.99f, amin = 1.f / 255.f, tmin = 1e-4f;
   const uint32_t qm = __builtin_amdgcn_readfirstlane(qmask);
+  uint64_t cb[4] = {0, 0, 0, 0};
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     const uint32_t hidx = (uint32_t)it + 1u;
@@ -240,6 +241,20 @@ __global__ void __launch_bounds__(256) seq(float* out, uint64_t* ticks, int iter
             Ts[q] = tw.x;
             C0[q] = fmaf(c0, tw.y, C0[q]); C1[q] = fmaf(c1, tw.y, C1[q]); C2[q] = fmaf(c2, tw.y, C2[q]);
             last[q] = ok ? hidx : last[q];
+          } else if (MODE == 4) {
+            // round 5: the long form WITHOUT scalar operations on vector-written compare masks (the two
+            // s_and_b64 of the shipped block): nested selects for `ok`, "took" asked of the weight
+            const float alpha = fminf(amax, o * __builtin_amdgcn_exp2f(pw));
+            const float a1 = pw <= 0.f ? alpha : 0.f;
+            const float ale = a1 >= amin ? a1 : 0.f;
+            float Tp;
+            asm("v_max_f32 %0, 0, %1" : "=v"(Tp) : "v"(Ts[q]));
+            const f2 tw = f2{Tp, Tp} * f2{1.f - ale, ale};
+            const bool stop = tw.x < tmin;
+            const float wgt = stop ? 0.f : tw.y;
+            Ts[q] = stop ? -fabsf(Ts[q]) : tw.x;
+            C0[q] = fmaf(c0, wgt, C0[q]); C1[q] = fmaf(c1, wgt, C1[q]); C2[q] = fmaf(c2, wgt, C2[q]);
+            last[q] = wgt > 0.f ? hidx : last[q];
           } else {
             const float alpha = fminf(amax, o * __builtin_amdgcn_exp2f(pw));
             const bool ok = (pw <= 0.f) & (alpha >= amin);
@@ -252,6 +267,13 @@ __global__ void __launch_bounds__(256) seq(float* out, uint64_t* ticks, int iter
             Ts[q] = stop ? -fabsf(Ts[q]) : tw.x;
             C0[q] = fmaf(c0, wgt, C0[q]); C1[q] = fmaf(c1, wgt, C1[q]); C2[q] = fmaf(c2, wgt, C2[q]);
             last[q] = (ok & !stop) ? hidx : last[q];
+            if (MODE == 5) {
+              // round 5's reverted "quadrant contributed" accumulation: one compare + scalar s_cmp / s_cselect / s_or
+              const uint64_t bit = __builtin_amdgcn_ballot_w64(wgt > 0.f) != 0ull ? (1ull << (it & 63)) : 0ull;
+              const uint64_t nb = cb[q] | bit;
+              cb[q] = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) |
+                      (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)nb);
+            }
           }
         }
       }
@@ -260,7 +282,7 @@ __global__ void __launch_bounds__(256) seq(float* out, uint64_t* ticks, int iter
   const uint64_t t1 = __builtin_readcyclecounter();
   float s = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) s += Ts[q] + C0[q] + C1[q] + C2[q] + (float)last[q];
+  for (int q = 0; q < 4; ++q) s += Ts[q] + C0[q] + C1[q] + C2[q] + (float)last[q] + (float)(uint32_t)(cb[q] ^ (cb[q] >> 32));
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
 }
@@ -295,8 +317,19 @@ void timeit(const char* name, K kern, int w, double inst_per_iter, int iters) {
 }
 
 #define RUN(OP, NAME, N) for (int w : {1, 4, 8}) timeit(NAME, k<OP>, w, 32.0 * N, 6000)
-int main() {
+int main(int argc, char** argv) {
   hipMalloc(&g_out, 256 * 8 * 256 * 4); hipMalloc(&g_ticks, 64);
+  if (argc > 1 && argv[1][0] == 'f') {      // `issue_model f`: the forward block's round-5 variants only
+    for (int rep = 0; rep < 2; ++rep)
+      for (int w : {4, 6, 8})
+        for (uint32_t qmask : {0x1u, 0x3u}) {
+          const double ev = __builtin_popcount(qmask);
+          timeit_q("seq long form, shipped (2 s_and on compare masks)", seq<0>, w, 20000, qmask, ev);
+          timeit_q("seq long form, no scalar op on a mask (r5 probe)", seq<4>, w, 20000, qmask, ev);
+          timeit_q("seq long form + contributed-bit accumulation", seq<5>, w, 20000, qmask, ev);
+        }
+    return 0;
+  }
   RUN(0, "v_fma_f32 (VOP3, 3 regs)", 1);  RUN(1, "v_mul_f32_e32", 1);  RUN(2, "v_fmac_f32_e32", 1);
   RUN(3, "v_pk_fma_f32", 1);  RUN(4, "v_pk_mul_f32", 1);  RUN(5, "v_pk_add_f32", 1);
   RUN(6, "v_exp_f32", 1);  RUN(7, "v_rcp_f32", 1);
