@@ -129,3 +129,22 @@ def test_committed_gpu_test_log_is_of_this_build():
     tail = text.strip().splitlines()[-1]
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= 125 and "failed" not in tail and "error" not in tail.lower(), tail
+
+
+def test_a_failing_rank_still_leaves_one_json_line(bench, capsys, monkeypatch):
+    """where the process survives (an exception), rank 0 prints ONE line with value 0 and an
+    `error` field; other ranks print nothing; nothing is printed twice."""
+    monkeypatch.setattr(bench, "_STATE", {"json_out": None, "printed": False})
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5"])
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    bench._error_line(RuntimeError("peer closed the connection"))
+    rec = json.loads(capsys.readouterr().out.strip())
+    assert rec["value"] == 0.0 and rec["n_gpus"] == 8 and "peer closed" in rec["error"] and rec["unit"] == "views/s"
+    monkeypatch.setenv("RANK", "3")
+    bench._error_line(RuntimeError("x"))
+    assert capsys.readouterr().out == ""
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(bench, "_STATE", {"json_out": None, "printed": True})     # the real line is already out
+    bench._error_line(RuntimeError("x"))
+    assert capsys.readouterr().out == ""
