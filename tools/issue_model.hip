@@ -287,6 +287,128 @@ __global__ void __launch_bounds__(256) seq(float* out, uint64_t* ticks, int iter
   if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+// The backward's per-contributing-entry reduction as it sits in raster_tiles.hip (wave_sum9_partials: four
+// v_permlane32_swap + two v_permlane16_swap folds, nine DPP adds, then the 8-lane partial sums staged in LDS by
+// eight lanes) and, every 32 entries, the finalising read of the staged rows by lane j (six 16-byte LDS reads,
+// the adds, three 16-byte stores to the entry's gradient slot).
+__global__ void __launch_bounds__(256) red(float* out, uint64_t* ticks, int iters) {
+  __shared__ float stage_all[4][32][3][8];
+  float (*stage)[3][8] = stage_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  float a = 0.01f * lane, b = 0.02f, c = 0.03f, d = 0.04f, e = 0.05f, f = 0.06f, g = 0.07f, h = 0.08f, i = 0.09f;
+  float4* slots = reinterpret_cast<float4*>(out) + (size_t)(blockIdx.x * 256 + threadIdx.x) * 3;
+  float acc = 0.f;
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    a += 1e-3f; e += 1e-3f; i += 1e-3f;
+    auto f32 = [](float x, float y) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+      return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+    auto f16 = [](float x, float y) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+      return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+    float r1 = f16(f32(a, b), f32(c, d)), r2 = f16(f32(e, f), f32(g, h)), r3 = i;
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "s_nop 1\n"
+        : "+v"(r1), "+v"(r2), "+v"(r3));
+    if ((lane & 7) == 7) {
+      float* st = &stage[it & 31][0][lane >> 3];
+      st[0] = r1; st[8] = r2; st[16] = r3;
+    }
+    if ((it & 31) == 31) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane < 32) {
+        const float4* sp = reinterpret_cast<const float4*>(&stage[lane][0][0]);
+        const float4 u0 = sp[0], u1 = sp[1], v0 = sp[2], v1 = sp[3], w0 = sp[4], w1 = sp[5];
+        slots[0] = make_float4(u0.x + u0.y, u0.z + u0.w, u1.x + u1.y, u1.z + u1.w);
+        slots[1] = make_float4(v0.x + v0.y, v0.z + v0.w, v1.x + v1.y, v1.z + v1.w);
+        slots[2] = make_float4((w0.x + w0.y) + (w0.z + w0.w) + (w1.x + w1.y) + (w1.z + w1.w), 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    acc += r1 + r2 + r3;
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+// round-5 probe: the same nine sums WITHOUT the DPP stage and the exec-masked staging stores -- after the two
+// permlane folds every lane writes its r1 / r2 (16 partial sums per value, one value per 16-lane row) and a
+// 3-step-DPP r3 to LDS with plain stores; every kEnt entries lane (e, v) sums its value's partials from LDS
+// (4 x 16-byte reads + 15 adds; 8 scalars for the ninth value), hands the total over through LDS, and lane e does
+// the finalising arithmetic and the three 16-byte slot stores as before.
+constexpr int kEnt = 5;
+__global__ void __launch_bounds__(256) red2(float* out, uint64_t* ticks, int iters) {
+  __shared__ float part_all[4][kEnt][3][64];
+  __shared__ float fin_all[4][kEnt][12];
+  float (*part)[3][64] = part_all[threadIdx.x >> 6];
+  float (*fin)[12] = fin_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  float a = 0.01f * lane, b = 0.02f, c = 0.03f, d = 0.04f, e = 0.05f, f = 0.06f, g = 0.07f, h = 0.08f, i = 0.09f;
+  float4* slots = reinterpret_cast<float4*>(out) + (size_t)(blockIdx.x * 256 + threadIdx.x) * 3;
+  float acc = 0.f;
+  int slot_e = 0;
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    a += 1e-3f; e += 1e-3f; i += 1e-3f;
+    auto f32 = [](float x, float y) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+      return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+    auto f16 = [](float x, float y) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+      return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+    const float r1 = f16(f32(a, b), f32(c, d)), r2 = f16(f32(e, f), f32(g, h));
+    float r3 = i;
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "s_nop 1\n"
+        : "+v"(r3));
+    part[slot_e][0][lane] = r1; part[slot_e][1][lane] = r2; part[slot_e][2][lane] = r3;
+    acc += r1 + r2 + r3;
+    if (++slot_e == kEnt) {
+      slot_e = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane < 8 * kEnt) {                     // lane = 8 * entry + value (values 0..7: rows of r1, r2)
+        const int en = lane >> 3, v = lane & 7;
+        const float4* sp = reinterpret_cast<const float4*>(&part[en][v >> 2][16 * (v & 3)]);
+        const float4 p0 = sp[0], p1 = sp[1], p2 = sp[2], p3 = sp[3];
+        fin[en][v] = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
+                     ((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w));
+      } else if (lane < 9 * kEnt) {              // the ninth value: eight 8-lane partials at lanes 7, 15, ..
+        const int en = lane - 8 * kEnt;
+        const float* sp = &part[en][2][7];
+        fin[en][8] = ((sp[0] + sp[8]) + (sp[16] + sp[24])) + ((sp[32] + sp[40]) + (sp[48] + sp[56]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane < kEnt) {
+        const float4* sp = reinterpret_cast<const float4*>(&fin[lane][0]);
+        const float4 u = sp[0], v = sp[1], w = sp[2];
+        slots[0] = make_float4((-0.3f * u.x - 0.1f * u.z) * 128.f, (-0.2f * u.z - 0.1f * u.x) * 128.f, -0.5f * u.y, -0.5f * u.w);
+        slots[1] = make_float4(-0.5f * v.x, v.z / 0.3f, v.y, v.w);
+        slots[2] = make_float4(w.x, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
+
 template <typename K>
 void timeit_q(const char* name, K kern, int w, int iters, uint32_t qmask, double evals_per_iter) {
   const int blocks = 256 * w;
@@ -319,6 +441,15 @@ void timeit(const char* name, K kern, int w, double inst_per_iter, int iters) {
 #define RUN(OP, NAME, N) for (int w : {1, 4, 8}) timeit(NAME, k<OP>, w, 32.0 * N, 6000)
 int main(int argc, char** argv) {
   hipMalloc(&g_out, 256 * 8 * 256 * 4); hipMalloc(&g_ticks, 64);
+  if (argc > 1 && argv[1][0] == 'b') {      // `issue_model b`: the backward's block and its per-entry reduction
+    hipFree(g_out); hipMalloc(&g_out, (size_t)256 * 8 * 256 * 48 + 4096);
+    for (int rep = 0; rep < 2; ++rep) {
+      for (int w : {2, 4}) timeit("backward block x4 quadrants / trip", blk<1>, w, 4.0, 20000);
+      for (int w : {2, 4}) timeit("backward 9-sum reduction + staging / entry", red, w, 1.0, 20000);
+      for (int w : {2, 4}) timeit("r5 probe: folds + plain LDS stores, sums from LDS", red2, w, 1.0, 20000);
+    }
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'f') {      // `issue_model f`: the forward block's round-5 variants only
     for (int rep = 0; rep < 2; ++rep)
       for (int w : {4, 6, 8})
