@@ -120,6 +120,9 @@ typedef struct PsRasterStateLayout {
   size_t checkpoint;  /* float[V][T][4][64][4]: per pixel (quadrant, lane) of a tile whose list is split in two
                          for the backward: transmittance after the list's first half and the colour composited
                          BEHIND it, divided by that transmittance (forward -> backward)             */
+  size_t cell_windows;/* uint32[N][4]: which 4x4-pixel cells the pair can reach with alpha >= alpha_min (visible
+                         entries; csrc/cell_window.h: a 64-bit mask over an 8x8 window of cells + its anchor,
+                         or a cell range) -- the tile forward's per-row cull (csrc/raster_cells.hip)     */
   size_t total;
 } PsRasterStateLayout;
 
@@ -547,9 +550,10 @@ const char* ps_status_string(int status);
 const char* ps_build_info(void);
 /* Layout version of the descriptor structs of this header (PsRasterDesc, PsEpipolarDesc, ...): bumped
  * whenever a struct grows or a field changes meaning.  A host built against an older header would hand
- * the library shorter structs (PsEpipolarDesc grew by tail_pad_in / tail_pad_out in version 4): check
+ * the library shorter structs (PsEpipolarDesc grew by tail_pad_in / tail_pad_out in version 4; PsRasterStateLayout by
+ * cell_windows in version 6): check
  * ps_abi_version() == PS_ABI_VERSION once after loading (pixelsplat_amd/_lib.py does). */
-#define PS_ABI_VERSION 5
+#define PS_ABI_VERSION 6
 int ps_abi_version(void);
 
 #ifdef __cplusplus

@@ -231,14 +231,18 @@ def blend_stats(st: ForwardState) -> tuple[int, int]:
     return int(out[0]), int(out[1])
 
 
-def quadrant_evaluations(st: ForwardState, alpha_min: float = 1.0 / 255.0) -> tuple[int, int]:
-    """(list entries that reach at least one 8x8 quadrant of their tile, (entry, quadrant) pairs) under the
-    product's conservative ellipse-vs-box bound (csrc/raster_tiles.hip quadrant_mask, restated in numpy): what
-    the tile kernels evaluate -- 64 lanes per pair -- before the last contributor / early termination cut the
-    walk.  A statistic for bench.py's `lane_efficiency` (contributing pairs / (pairs x 64)); not a parity path."""
+def box_evaluations(st: ForwardState, box: int = 8, alpha_min: float = 1.0 / 255.0) -> dict:
+    """What a tile kernel that culls per `box` x `box` pixel block evaluates (box 8: the 8x8 quadrants of
+    csrc/raster_tiles.hip's backward; box 4: the 4x4 cells of csrc/raster_cells.hip), under the product's conservative
+    ellipse-vs-box bound (quadrant_mask / cell masks, restated in numpy), over the part of every tile list up to
+    the tile's last contributor.  Returns dict(entries = list entries that reach at least one block, pairs =
+    (entry, block) pairs, lanes = pairs x box^2, row_steps = sum over groups of four blocks (one wave64 of
+    16-lane rows) of the longest of the four per-block queues -- the steps a wave of four independent rows
+    takes; only meaningful for box 4).  A statistic for bench.py's `lane_efficiency*`; not a parity path."""
     n = st.num_rendered
+    nb = 16 // box
     if n == 0:
-        return 0, 0
+        return dict(entries=0, pairs=0, lanes=0, row_steps=0)
     gx = (st.params.W + 15) // 16
     cnt = (st.ranges[:, 1] - st.ranges[:, 0]).astype(np.int64)
     tile = np.repeat(np.arange(cnt.size), cnt)
@@ -258,13 +262,15 @@ def quadrant_evaluations(st: ForwardState, alpha_min: float = 1.0 / 255.0) -> tu
     co = st.conic_opacity[ids].astype(np.float32)
     k = np.float32(1.4426950408889634)
     A, B, Cq, op = -0.5 * k * co[:, 0], -k * co[:, 1], -0.5 * k * co[:, 2], co[:, 3]
+    per_block = np.zeros((cnt.size, nb * nb), np.int64)
     with np.errstate(divide="ignore", invalid="ignore"):
         tau = np.log2(op / np.float32(alpha_min))
         pd = (A < 0) & (Cq < 0) & (4 * A * Cq - B * B > 0)
         pairs = np.zeros(ids.size, np.int64)
-        for q in range(4):
-            bx, by = x0 + 8 * (q & 1), y0 + 8 * (q >> 1)
-            dxlo, dxhi, dylo, dyhi = px - (bx + 7), px - bx, py - (by + 7), py - by
+        e = np.float32(box - 1)
+        for q in range(nb * nb):
+            bx, by = x0 + box * (q % nb), y0 + box * (q // nb)
+            dxlo, dxhi, dylo, dyhi = px - (bx + e), px - bx, py - (by + e), py - by
             ex = np.where(dxlo > 0, dxlo, np.where(dxhi < 0, dxhi, 0))
             ey = np.where(dylo > 0, dylo, np.where(dyhi < 0, dyhi, 0))
             qmin = np.full(ids.size, 3.0e38, np.float32)
@@ -273,8 +279,24 @@ def quadrant_evaluations(st: ForwardState, alpha_min: float = 1.0 / 255.0) -> tu
             dx = np.minimum(dxhi, np.maximum(dxlo, -B * ey / (2 * A)))
             qmin = np.where(ey != 0, np.minimum(qmin, -(A * dx * dx + B * dx * ey + Cq * ey * ey)), qmin)
             may = ((ex == 0) & (ey == 0)) | ~(qmin > tau + 1e-4 * np.abs(tau) + 1e-3)
-            pairs += (tau >= 0) & (~pd | may)
-    return int((pairs > 0).sum()), int(pairs.sum())
+            hit = (tau >= 0) & (~pd | may)
+            pairs += hit
+            per_block[:, q] = np.bincount(tile[hit], minlength=cnt.size)
+    # four blocks = the four 16-lane rows of one wave64: box 4 -> the 2x2 cells of an 8x8 quadrant
+    if nb == 4:
+        g = per_block.reshape(-1, 2, 2, 2, 2).transpose(0, 1, 3, 2, 4).reshape(-1, 4)
+        row_steps = int(g.max(axis=1).sum())
+    else:
+        row_steps = int(per_block.sum())
+    total = int(pairs.sum())
+    return dict(entries=int((pairs > 0).sum()), pairs=total, lanes=total * box * box, row_steps=row_steps)
+
+
+def quadrant_evaluations(st: ForwardState, alpha_min: float = 1.0 / 255.0) -> tuple[int, int]:
+    """(list entries that reach at least one 8x8 quadrant of their tile, (entry, quadrant) pairs): box_evaluations
+    with box 8 -- what the 8x8-quadrant kernels evaluate, 64 lanes per pair."""
+    r = box_evaluations(st, 8, alpha_min)
+    return r["entries"], r["pairs"]
 
 
 def backward(st: ForwardState, dL_dimage):

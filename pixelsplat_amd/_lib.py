@@ -38,7 +38,7 @@ class PsRasterStateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "records", "rects", "sorted_idx", "sorted_rect", "n_vis", "final_T", "n_contrib",
         "tile_end", "tile_ranges", "num_rendered", "tile_order", "clamp_bits", "checkpoint",
-        "total")]
+        "cell_windows", "total")]
 
 
 class PsEpipolarDesc(C.Structure):
@@ -83,7 +83,7 @@ EXPORTS = [
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
     "ps_abi_version",
 ]
-PS_ABI_VERSION = 5      # include/pixelsplat_hip.h
+PS_ABI_VERSION = 6      # include/pixelsplat_hip.h
 
 _lib = None
 

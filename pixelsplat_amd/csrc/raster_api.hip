@@ -128,7 +128,7 @@ namespace {
 struct FwdPtrs {
   float* records; uint2* rects; uint32_t* sorted_idx; uint2* sorted_rect; uint32_t* n_vis;
   float* final_T; uint32_t* n_contrib; float4* checkpoint; uint32_t* tile_end; uint32_t* tile_ranges;
-  uint32_t* num_rendered; uint32_t* tile_order; uint8_t* clamp_bits;
+  uint32_t* num_rendered; uint32_t* tile_order; uint8_t* clamp_bits; uint4* cell_windows;
   uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *block_hist, *pass_info, *bin_counts;
 };
 FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
@@ -145,6 +145,7 @@ FwdPtrs fwd_ptrs(const PsRasterDesc& d, void* state, void* temp) {
   p.num_rendered = (uint32_t*)(sb + L.num_rendered);
   p.tile_order = (uint32_t*)(sb + L.tile_order);
   p.clamp_bits = (uint8_t*)(sb + L.clamp_bits);
+  p.cell_windows = (uint4*)(sb + L.cell_windows);
   p.keys_a = (uint32_t*)(tb + T.keys_a); p.keys_b = (uint32_t*)(tb + T.keys_b);
   p.vals_a = (uint32_t*)(tb + T.vals_a); p.vals_b = (uint32_t*)(tb + T.vals_b);
   p.block_hist = (uint32_t*)(tb + T.block_hist); p.bin_counts = (uint32_t*)(tb + T.bin_counts);
@@ -178,7 +179,7 @@ int ps_raster_forward_plan(const PsRasterDesc* d, const float* means, const floa
   {
     Scope sc(G_PRE_FWD, st);
     launch_preprocess_forward(*d, means, cov, sh, colors, opacity, view_params, p.records,
-                              p.keys_a, p.rects, out_radii, p.clamp_bits, true,
+                              p.keys_a, p.rects, out_radii, p.clamp_bits, p.cell_windows, true,
                               !(d->flags & PS_FLAG_DEFER_SH_COLORS), st);
   }
   {
@@ -205,8 +206,8 @@ int ps_raster_forward_colors(const PsRasterDesc* d, const float* means, const fl
   const FwdPtrs p = fwd_ptrs(*d, state, temp);
   Scope sc(G_PRE_FWD, st);
   launch_preprocess_forward(*d, means, nullptr, sh, nullptr, nullptr, view_params, p.records,
-                            p.keys_a, p.rects, const_cast<int32_t*>(radii), p.clamp_bits, false,
-                            true, st);
+                            p.keys_a, p.rects, const_cast<int32_t*>(radii), p.clamp_bits, p.cell_windows,
+                            false, true, st);
   return check_launch();
 }
 
@@ -234,9 +235,15 @@ int ps_raster_forward_tiles(const PsRasterDesc* d, const float* view_params, flo
   hipStream_t st = (hipStream_t)stream;
   const FwdPtrs p = fwd_ptrs(*d, state, temp);
   Scope sc(G_TILES_FWD, st);
-  launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list,
-                       clamp_capacity(list_capacity), view_params, out_color, p.final_T,
-                       p.n_contrib, p.checkpoint, p.tile_end, st);
+  // PS_FORWARD_QUADRANTS=1: the round-5 8x8-quadrant forward (A/B runs: tools/ab_cells.sh); same results
+  static const bool old_forward = [] { const char* e = getenv("PS_FORWARD_QUADRANTS"); return e && e[0] == '1'; }();
+  if (old_forward)
+    launch_tiles_forward(*d, p.records, p.tile_order, p.tile_ranges, point_list, clamp_capacity(list_capacity),
+                         view_params, out_color, p.final_T, p.n_contrib, p.checkpoint, p.tile_end, st);
+  else
+    launch_tiles_forward_rows(*d, p.records, p.cell_windows, p.tile_order, p.tile_ranges, point_list,
+                              clamp_capacity(list_capacity), view_params, out_color, p.final_T, p.n_contrib,
+                              p.checkpoint, p.tile_end, st);
   return check_launch();
 }
 

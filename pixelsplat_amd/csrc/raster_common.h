@@ -117,6 +117,7 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
   s.clamp_bits = o; o = align_up(o + m.N);
   s.checkpoint = o; o = align_up(o + (size_t)m.V * m.tiles * kTile * kTile * 16);
+  s.cell_windows = o; o = align_up(o + m.N * 16);
   s.total = o;
   return s;
 }
@@ -125,8 +126,8 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, uint8_t* clamp_bits, bool geometry,
-                               bool sh_colors, hipStream_t st);
+                               uint2* rects, int32_t* radii, uint8_t* clamp_bits, uint4* cell_windows,
+                               bool geometry, bool sh_colors, hipStream_t st);
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                  uint32_t* vals_b, uint32_t* block_hist, uint32_t* pass_info, uint32_t* sorted_idx,
@@ -146,6 +147,13 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
                           uint32_t capacity, const float* view_params, float* out_color,
                           float* final_T, uint32_t* n_contrib, float4* checkpoint,
                           uint32_t* tile_end, hipStream_t st);
+
+// the tile forward on 4x4-pixel cells, a wave64 = four 16-lane rows (raster_cells.hip)
+void launch_tiles_forward_rows(const PsRasterDesc& d, const float* records, const uint4* cell_windows,
+                               const uint32_t* tile_order, const uint32_t* tile_ranges,
+                               const uint32_t* point_list, uint32_t capacity, const float* view_params,
+                               float* out_color, float* final_T, uint32_t* n_contrib, float4* checkpoint,
+                               uint32_t* tile_end, hipStream_t st);
 
 void launch_backward_task_order(const PsRasterDesc& d, const uint32_t* tile_ranges,
                                 const uint32_t* tile_end, uint32_t capacity, uint32_t* task_order,

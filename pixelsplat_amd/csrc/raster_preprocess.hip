@@ -25,6 +25,7 @@
 //          (kSmallFlag | width-1 | ymin | xmin for rects of <= 4 tiles, else 0)
 //   [8..11] r, g, b, clamp bits
 #include "raster_common.h"
+#include "cell_window.h"
 #include "sh_math.h"
 
 #include <cstdlib>
@@ -143,7 +144,8 @@ geometry_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
                         const float* __restrict__ cov, const float* __restrict__ colors,
                         const float* __restrict__ opacity, const float* __restrict__ view_params,
                         float* __restrict__ records, uint32_t* __restrict__ keys,
-                        uint2* __restrict__ rects, int32_t* __restrict__ radii) {
+                        uint2* __restrict__ rects, int32_t* __restrict__ radii,
+                        uint4* __restrict__ cell_windows) {
   const int G = d.n_gaussians, vps = d.views_per_scene, H = d.height, W = d.width;
   const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,6 +168,7 @@ geometry_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
       float4* r = reinterpret_cast<float4*>(records + vg * kRecFloats);
       r[0] = make_float4(o.px, o.py, o.con_x, o.con_y);
       r[1] = make_float4(o.con_z, opac, o.tvz, __uint_as_float(packed_small_rect(o, gy)));
+      cell_windows[vg] = cell_window(o.px, o.py, o.con_x, o.con_y, o.con_z, opac, d.alpha_min);
       if (colors != nullptr) {   // colors_precomp: verbatim, no clamp
         const float* cp = colors + vg * 3;
         r[2] = make_float4(cp[0], cp[1], cp[2], __uint_as_float(0u));
@@ -284,7 +287,7 @@ preprocess_fused_kernel(PsRasterDesc d, const float* __restrict__ means,
                         const float* __restrict__ opacity, const float* __restrict__ view_params,
                         float* __restrict__ records, uint32_t* __restrict__ keys,
                         uint2* __restrict__ rects, int32_t* __restrict__ radii,
-                        uint8_t* __restrict__ clamp_out) {
+                        uint8_t* __restrict__ clamp_out, uint4* __restrict__ cell_windows) {
   constexpr int GPW = kFusedGpw;
   __shared__ __attribute__((aligned(16))) float slab[GPW * 75 + 4];
   __shared__ __attribute__((aligned(16))) float vslab[kFusedViews * PS_VIEW_STRIDE];
@@ -344,13 +347,15 @@ preprocess_fused_kernel(PsRasterDesc d, const float* __restrict__ means,
   r[1] = make_float4(o.con_z, opac, o.tvz, __uint_as_float(packed_small_rect(o, gy)));
   r[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
   clamp_out[vg] = (uint8_t)clamp_bits;   // compact copy for the backward
+  // which 4x4 cells the pair can reach (the tile forward's cull, cell_window.h)
+  cell_windows[vg] = cell_window(o.px, o.py, o.con_x, o.con_y, o.con_z, opac, d.alpha_min);
 }
 
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,
                                const float* sh, const float* colors, const float* opacity,
                                const float* view_params, float* records, uint32_t* keys,
-                               uint2* rects, int32_t* radii, uint8_t* clamp_bits, bool geometry,
-                               bool sh_colors, hipStream_t st) {
+                               uint2* rects, int32_t* radii, uint8_t* clamp_bits, uint4* cell_windows,
+                               bool geometry, bool sh_colors, hipStream_t st) {
   // LDS staging needs an odd float stride per Gaussian (K = 1, 9, 25), at most 75
   const bool lds = ((d.sh_coeffs * 3) & 1) && d.sh_coeffs * 3 <= 75;
   static const bool fused_ok = [] { const char* e = getenv("PS_PREPROCESS_FUSED"); return !e || atoi(e) != 0; }();
@@ -359,7 +364,7 @@ void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const 
     dim3 grid((d.n_gaussians + kFusedGpw - 1) / kFusedGpw, d.n_scenes), block(kWave);
 #define PS_FUSED(DEG)                                                                          \
   hipLaunchKernelGGL((preprocess_fused_kernel<DEG>), grid, block, 0, st, d, means, cov, sh,     \
-                     opacity, view_params, records, keys, rects, radii, clamp_bits)
+                     opacity, view_params, records, keys, rects, radii, clamp_bits, cell_windows)
     switch (d.sh_degree) {
       case 0: PS_FUSED(0); break;
       case 1: PS_FUSED(1); break;
@@ -373,7 +378,7 @@ void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const 
   if (geometry) {
     dim3 grid((d.n_gaussians + 255) / 256, d.n_scenes), block(256);
     hipLaunchKernelGGL(geometry_forward_kernel, grid, block, 0, st, d, means, cov, colors,
-                       opacity, view_params, records, keys, rects, radii);
+                       opacity, view_params, records, keys, rects, radii, cell_windows);
   }
   if (!sh || !sh_colors) return;
   const int deg = d.sh_degree;
