@@ -66,7 +66,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     rebuilt = False
     procs = []
     units = SOURCES + extra
-    hashes = unit_hashes([u for u in units if u[0] != "raster_api.hip"])
+    # every unit, raster_api.hip included: a unit's hash covers its source, the shared headers and its BASE flags,
+    # not the -DPS_BUILD_HASHES stamp raster_api.hip is compiled with, so the stamp is not self-referential
+    hashes = unit_hashes(units)
     stamp = os.path.join(CSRC, ".build_hashes")
     hashes_changed = (not os.path.exists(stamp)) or open(stamp).read() != hashes
     for name, flags in units:

@@ -284,6 +284,35 @@ class _JoinFeatureGrad(torch.autograd.Function):
         return g, None
 
 
+_PARKED: list = []     # (events, tensors ...) a FeatureGradBatch could not wait for when it was released
+
+
+def _any_capture_in_progress() -> bool:
+    """Is this thread's current stream capturing?  (All torch exposes.  A `global`-mode capture begun on another
+    thread is not visible from here: _release therefore asks the events with query() first -- which never blocks
+    and is legal during any capture -- and only waits on the host for events that are really still pending.)"""
+    try:
+        if not torch.cuda.is_available():
+            return False
+        return bool(torch.cuda.is_current_stream_capturing())
+    except Exception:
+        return True
+
+
+def _drain_parked() -> None:
+    """Drop the parked references whose events have completed (event.query() never blocks and is legal during a
+    capture on another stream)."""
+    keep = []
+    for entry in _PARKED:
+        try:
+            if all(ev.query() for ev in entry[0]):
+                continue
+        except Exception:
+            pass
+        keep.append(entry)
+    _PARKED[:] = keep
+
+
 class FeatureGradBatch:
     """Defers the feature-map gradients of attention layers that share one geometry and one
     feature map (the layers of an EpipolarTransformer) so that they are scattered in ONE pass
@@ -323,20 +352,34 @@ class FeatureGradBatch:
 
     def _release(self) -> None:
         """The join node never ran (an exception between flush and join, a gradient nobody asked for):
-        what the side stream is reading must outlive its kernels -- wait for them on the host before the
-        references go (never reached inside a capture: a capture that ends with the side stream unjoined
-        fails on its own)."""
-        done, self._done = self._done, None
-        pending = [done] if (done is not None and self._keep is not None) else []
-        if getattr(self, "_bins_inputs", None) is not None:
-            pending.append(self._bins_inputs[2])
-        for ev in pending:
-            try:
-                if not torch.cuda.is_current_stream_capturing():
-                    ev.synchronize()
-            except Exception:
-                pass
-        self._keep = self._bins_inputs = None
+        what the side stream is reading must outlive its kernels.  Outside any capture: wait for them on the
+        host before the references go.  While ANY stream of the process may be capturing (this can run from
+        the garbage collector, on whatever thread; a host-side event wait would invalidate a `global`-mode
+        capture in progress) or when the wait itself fails: the references are parked on a module-level list
+        that the next flush / release outside a capture drains.  Every attribute is read with a default: __del__
+        also runs for an object whose __init__ raised."""
+        done, keep = getattr(self, "_done", None), getattr(self, "_keep", None)
+        bins_inputs = getattr(self, "_bins_inputs", None)
+        self._done = self._keep = self._bins_inputs = None
+        pending = [done] if (done is not None and keep is not None) else []
+        if bins_inputs is not None:
+            pending.append(bins_inputs[2])
+        if not pending:
+            return
+        _drain_parked()
+        try:
+            if all(ev.query() for ev in pending):      # the side stream is done already: nothing to wait for
+                return
+        except Exception:
+            pass
+        if _any_capture_in_progress():
+            _PARKED.append((pending, keep, bins_inputs))
+            return
+        try:
+            for ev in pending:
+                ev.synchronize()
+        except Exception:
+            _PARKED.append((pending, keep, bins_inputs))
 
     def register(self) -> int:
         if self.pending:

@@ -47,7 +47,7 @@ class ConnectedStep(nn.Module):
             head_cfg = EncoderEpipolarHeadCfg(
                 d_feature=d_feature, num_monocular_samples=32, num_surfaces=1, predict_opacity=False,
                 gaussians_per_pixel=3, gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 4),
-                opacity_mapping=OpacityMappingCfg(0.0, 0.01, 1), use_transmittance=False)
+                opacity_mapping=OpacityMappingCfg(0.0, 0.0, 1), use_transmittance=False)
         self.head = EncoderEpipolarHead(head_cfg)
         self.decoder = DecoderSplattingCUDA(DecoderSplattingCUDACfg("splatting_cuda"),
                                             SimpleNamespace(background_color=list(background)))

@@ -84,7 +84,7 @@ def test_library_stamp_is_the_hash_of_its_sources():
     info = lib.ps_build_info().decode()
     units = build.SOURCES + [(f, []) for f in sorted(os.listdir(build.CSRC))
                              if f.endswith(".hip") and f not in {s for s, _ in build.SOURCES}]
-    want = build.unit_hashes([u for u in units if u[0] != "raster_api.hip"])
+    want = build.unit_hashes(units)
     assert want in info, "libpixelsplat_hip.so was not built from the sources in the tree: run python -m pixelsplat_amd.build"
     stamp = dict(tok.split(":") for tok in want.split())
     assert {"raster_tiles", "raster_backward", "epipolar_attention", "gaussian_adapter", "depth_sampler"} <= set(stamp)
@@ -114,15 +114,17 @@ def test_committed_gpu_test_log_is_of_this_build():
 
     from pixelsplat_amd import build
 
-    path = os.path.join(ROOT, "profiles", "r5_gpu_tests.log")
-    assert os.path.exists(path), "no committed GPU-suite log: run tools/profile_all_configs.sh r5 tests on the GPU box"
+    logs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_gpu_tests\.log", f)),
+                  key=lambda f: int(f[1:f.index("_")]))
+    assert logs, "no committed GPU-suite log: run tools/profile_all_configs.sh r<N> tests on the GPU box"
+    path = os.path.join(ROOT, "profiles", logs[-1])      # the newest round's
     text = open(path).read()
     first = text.splitlines()[0]
     assert first.startswith("build:"), first[:80]
     stamped = dict(tok.split(":", 1) for tok in first.split("|", 1)[-1].split() if ":" in tok)
     units = build.SOURCES + [(f, []) for f in sorted(os.listdir(build.CSRC))
                              if f.endswith(".hip") and f not in {s_ for s_, _ in build.SOURCES}]
-    want = dict(tok.split(":") for tok in build.unit_hashes([u for u in units if u[0] != "raster_api.hip"]).split())
+    want = dict(tok.split(":") for tok in build.unit_hashes(units).split())
     assert set(want) <= set(stamped), sorted(set(want) - set(stamped))
     stale = {u: (stamped[u], h) for u, h in want.items() if stamped[u] != h}
     assert not stale, f"the GPU suite was last run on other code than the tree holds: {stale}"
@@ -148,3 +150,35 @@ def test_a_failing_rank_still_leaves_one_json_line(bench, capsys, monkeypatch):
     monkeypatch.setattr(bench, "_STATE", {"json_out": None, "printed": True})     # the real line is already out
     bench._error_line(RuntimeError("x"))
     assert capsys.readouterr().out == ""
+
+
+def test_newest_counter_summaries_carry_a_commit_of_this_history():
+    """round 5's counter files were stamped with a round-4 commit (a stale .git_sha).  The
+    newest round's profiles/r*_pmc_*.json must name a commit that is an ancestor of (or equal to) HEAD and not older
+    than the last commit that touched the kernels -- tools/gpu_call.sh refreshes .git_sha before every gpurun call."""
+    import re
+    import subprocess
+
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git history here (GPU box snapshot)")
+    prof = os.path.join(ROOT, "profiles")
+    files = [f for f in os.listdir(prof) if re.fullmatch(r"r\d+_\w*pmc_\w+\.json", f)]
+    assert files, "no committed counter summary"
+    newest = max(int(re.match(r"r(\d+)_", f).group(1)) for f in files)
+    if newest < 6:
+        pytest.skip("counter summaries of rounds before the stamp was fixed")
+
+    def git(*a):
+        return subprocess.run(["git", "-C", ROOT, *a], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+    last_csrc = git("log", "-1", "--format=%H", "--", "pixelsplat_amd/csrc", "include").stdout.strip()
+    for f in sorted(f for f in files if f.startswith(f"r{newest}_")):
+        rec = json.load(open(os.path.join(prof, f)))
+        sha = (rec.get("git") or "").replace("-dirty", "")
+        assert re.fullmatch(r"[0-9a-f]{40}", sha), f"{f}: no commit stamp ({rec.get('git')!r})"
+        assert git("merge-base", "--is-ancestor", sha, "HEAD").returncode == 0, f"{f}: {sha} is not in this history"
+        # the summary's per-unit source hashes are what pairs it with a build (bench.py); the commit must at least
+        # not predate the last kernel change, unless the tree was dirty with exactly that change when it was taken
+        if "-dirty" not in (rec.get("git") or ""):
+            assert git("merge-base", "--is-ancestor", last_csrc, sha).returncode == 0, \
+                f"{f}: stamped {sha[:12]}, older than the last kernel commit {last_csrc[:12]}"

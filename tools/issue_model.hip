@@ -409,6 +409,129 @@ __global__ void __launch_bounds__(256) red2(float* out, uint64_t* ticks, int ite
   if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+
+// round-6 probe: what the backward's nine sums cost PER WAVE STEP when a wave64 is four
+// independent 16-lane rows, each on its own (entry, 4x4 cell) pair -- the forward's layout (csrc/raster_cells.hip)
+// carried over to the backward.  Reduction + staging + the finalising read every 32 steps, nothing else (the
+// per-pixel block is the `blk<1>` row above: the same 64-lane instruction stream whatever the lanes hold).
+//   MODE 0  nine values x four DPP row_shr adds (1, 2, 4, 8): the row total lands in lane 15 of each row, which
+//           stages its nine sums with three exec-masked LDS stores
+//   MODE 1  "fold" tree inside the row: two values share a register after each level (DPP adds with bank masks
+//           for the 8- and 4-lane levels, quad_perm for the last two): 8 + 4 + 3 + 1 instructions for eight values,
+//           4 for the ninth; the eight totals sit in the even lanes, one LDS store stages them
+//   MODE 2  "systolic": lane p works on item t - p, the nine sums travel with their item from lane to lane
+//           (v_add_f32_dpp row_shr:1, zero shifted in at lane 0) and arrive complete at lane 15, which stages
+//           them; the accumulating FMAs of the block become multiply + DPP add (7 more instructions)
+template <int MODE>
+__global__ void __launch_bounds__(256) rowred(float* out, uint64_t* ticks, int iters) {
+  __shared__ float stage_all[4][32][4][12];          // [step][row][9 sums]
+  float (*stage)[4][12] = stage_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63, row = lane >> 4, it16 = lane & 15;
+  float a = 0.01f * lane, b = 0.02f, c = 0.03f, d = 0.04f, e = 0.05f, f = 0.06f, g = 0.07f, h = 0.08f, i = 0.09f;
+  float4* slots = reinterpret_cast<float4*>(out) + (size_t)(blockIdx.x * 256 + threadIdx.x) * 6;
+  float acc = 0.f;
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0;   // MODE 2: the travelling sums
+  const uint64_t odd2 = 0xCCCCCCCCCCCCCCCCull;       // lanes with bit 1 set
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    a += 1e-3f; e += 1e-3f; i += 1e-3f;
+    if (MODE == 0) {
+      float v0 = a, v1 = b, v2 = c, v3 = d, v4 = e, v5 = f, v6 = g, v7 = h, v8 = i;
+#define PS_STEP(N) \
+      "v_add_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %4, %4, %4 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %5, %5, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %6, %6, %6 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %7, %7, %7 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+      "v_add_f32_dpp %8, %8, %8 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      asm volatile("s_nop 1\n" PS_STEP(1) PS_STEP(2) PS_STEP(4) PS_STEP(8) "s_nop 1\n"
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
+#undef PS_STEP
+      if (it16 == 15) {
+        float4* st = reinterpret_cast<float4*>(&stage[it & 31][row][0]);
+        st[0] = make_float4(v0, v1, v2, v3); st[1] = make_float4(v4, v5, v6, v7); st[2].x = v8;
+      }
+      acc += v0;
+    } else if (MODE == 1) {
+      float v0 = a, v1 = b, v2 = c, v3 = d, v4 = e, v5 = f, v6 = g, v7 = h, v8 = i, t1, t2;
+      asm volatile(
+          "s_nop 1\n"
+          // level 1: (v0,v1) (v2,v3) (v4,v5) (v6,v7) -> v0 v2 v4 v6: lanes 0-7 first value, 8-15 second
+          "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+          "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+          "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+          "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+          "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+          "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+          "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+          "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+          "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+          // level 2: (v0,v2) (v4,v6) -> v0 v4: banks 0, 2 from the first register, 1, 3 from the second
+          "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+          "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+          "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+          "v_add_f32_dpp %4, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+          "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+          // level 3: (v0,v4) -> v0: lanes 0,1 of a quad from v0, lanes 2,3 from v4
+          "v_add_f32_dpp %9, %0, %0 quad_perm:[2,3,2,3] row_mask:0xf bank_mask:0xf\n"
+          "v_add_f32_dpp %10, %4, %4 quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n"
+          "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+          "v_cndmask_b32 %0, %9, %10, %11\n"
+          // level 4
+          "s_nop 1\n"
+          "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+          "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+          "s_nop 1\n"
+          : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8),
+            "=&v"(t1), "=&v"(t2)
+          : "s"(odd2));
+      // even lane 2 k of a row holds total number k' (a fixed permutation of 0..7); lane 1 stores the ninth
+      if ((lane & 1) == 0) stage[it & 31][row][it16 >> 1] = v0;
+      if (it16 == 1) stage[it & 31][row][8] = v8;
+      acc += v0;
+    } else {
+      // the block's nine contributions (a .. i stand for them); seven of them were the product inside an FMA
+      float m0 = b * a, m1 = c * a, m2 = d * a, m3 = f * e, m4 = g * e, m5 = h * e, m6 = i * a;
+      asm volatile(
+          "s_nop 1\n"
+          "v_add_f32_dpp %0, %0, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %1, %1, %10 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %2, %2, %11 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %3, %3, %12 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %4, %4, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %5, %5, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %6, %6, %15 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %7, %7, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %8, %8, %17 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8)
+          : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(a), "v"(e));
+      if (it16 == 15) {
+        float4* st = reinterpret_cast<float4*>(&stage[it & 31][row][0]);
+        st[0] = make_float4(s0, s1, s2, s3); st[1] = make_float4(s4, s5, s6, s7); st[2].x = s8;
+      }
+      acc += s0;
+    }
+    if ((it & 31) == 31) {     // 32 steps x 4 rows = 128 (entry, cell) results: two per lane
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4* sp = reinterpret_cast<const float4*>(&stage[(lane >> 2) + 16 * u][lane & 3][0]);
+        const float4 u0 = sp[0], u1 = sp[1], u2 = sp[2];
+        slots[3 * u + 0] = make_float4((-0.3f * u0.x - 0.1f * u0.z) * 128.f, (-0.2f * u0.z - 0.1f * u0.x) * 128.f, -0.5f * u0.y, -0.5f * u0.w);
+        slots[3 * u + 1] = make_float4(-0.5f * u1.x, u1.z / 0.3f, u1.y, u1.w);
+        slots[3 * u + 2] = make_float4(u2.x, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const uint64_t t1c = __builtin_readcyclecounter();
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1c - t0;
+}
+
 template <typename K>
 void timeit_q(const char* name, K kern, int w, int iters, uint32_t qmask, double evals_per_iter) {
   const int blocks = 256 * w;
@@ -447,6 +570,17 @@ int main(int argc, char** argv) {
       for (int w : {2, 4}) timeit("backward block x4 quadrants / trip", blk<1>, w, 4.0, 20000);
       for (int w : {2, 4}) timeit("backward 9-sum reduction + staging / entry", red, w, 1.0, 20000);
       for (int w : {2, 4}) timeit("r5 probe: folds + plain LDS stores, sums from LDS", red2, w, 1.0, 20000);
+    }
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'r') {      // `issue_model r`: the backward's reduction per wave step on 16-lane rows
+    hipFree(g_out); hipMalloc(&g_out, (size_t)256 * 8 * 256 * 96 + 4096);
+    for (int rep = 0; rep < 2; ++rep) {
+      for (int w : {4, 5}) timeit("backward block x4 quadrants / trip", blk<1>, w, 4.0, 20000);
+      for (int w : {4, 5}) timeit("shipped: 9-sum reduction + staging / entry", red, w, 1.0, 20000);
+      for (int w : {4, 5}) timeit("rows: 36 DPP row_shr adds + staging / wave step", rowred<0>, w, 1.0, 20000);
+      for (int w : {4, 5}) timeit("rows: fold tree (20 DPP) + staging / wave step", rowred<1>, w, 1.0, 20000);
+      for (int w : {4, 5}) timeit("rows: systolic sums (9 DPP + 7 mul) / wave step", rowred<2>, w, 1.0, 20000);
     }
     return 0;
   }
