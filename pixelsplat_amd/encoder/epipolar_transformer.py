@@ -174,14 +174,26 @@ class EpipolarTransformer(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
+        # The parameters enter the side stream's graph through an alias made HERE, on the main stream: autograd
+        # replays a node on its forward's stream, so without it the fold's backward hands the parameter gradients
+        # to their AccumulateGrad nodes from the side stream -- and under DistributedDataParallel, which creates
+        # those nodes at construction (on the stream current then) and keeps them, torch warns "AccumulateGrad
+        # node's stream does not match" and synchronises every step (tests/test_ddp_gpu.py).  An alias is
+        # metadata only, forward and backward: no kernel.
+        def on_main(wd: dict) -> dict:
+            return {k: (t.view_as(t) if isinstance(t, Tensor) and t.is_leaf and t.requires_grad else t)
+                    for k, t in wd.items()}
+
+        weights = [None if len(attn.fn.attend._forward_hooks) > 0 else on_main(self._layer_weights(attn, view_emb))
+                   for attn, _ in self.transformer.layers]
         side.wait_stream(main)
         folds = []
         with torch.cuda.stream(side):
-            for attn, _ in self.transformer.layers:
-                if len(attn.fn.attend._forward_hooks) > 0:
+            for wd in weights:
+                if wd is None:
                     folds.append(None)        # hooked layers take the unfused path: nothing to fold
                     continue
-                f = fold_attention_weights(**self._layer_weights(attn, view_emb))
+                f = fold_attention_weights(**wd)
                 done = torch.cuda.Event()
                 done.record(side)
                 for t in f:
