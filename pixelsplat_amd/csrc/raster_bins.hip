@@ -13,6 +13,8 @@
 // cheap integer VALU instead of the reference's 5-6 radix passes over D 12-byte pairs.
 #include "raster_common.h"
 
+#include <cstdlib>
+
 namespace ps {
 
 template <bool WRITE>
@@ -76,6 +78,159 @@ bin_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
       }
     }
     if (!WRITE && tile_ok) *c = k;
+  }
+}
+
+
+// Write pass, entry-parallel (round 6).  bin_kernel<true> above walks every entry of the chunk with 64 lanes = 64
+// tiles of which ~5 are covered: 77 M wave instructions for 13.9 M list entries at BASELINE configs[1], 0.22 ms.
+// Here the chunk's (entry, tile) pairs are EXPANDED into LDS in entry-major order (a thread owns four consecutive
+// entries; a block scan of their tile counts places them) and stably counting-sorted by tile id, the ranking being
+// the radix sort's (raster_sort.hip): per 64 pairs, ceil(log2 tiles) ballots build the mask of lanes on the same
+// tile, rank = popcount below me, a per-wave LDS counter per tile carries the running count across the wave's
+// batches, and a prefix over the waves turns ranks into positions.  Entry-major order + a stable sort by tile =
+// every tile list in (depth, id) order: the same bytes bin_kernel<true> writes.  A chunk whose pairs do not fit
+// kPairCap is processed in pieces of consecutive entries (the per-tile positions carry over).
+constexpr int kPairCap = 4096;              // pairs per piece (16 KB of LDS)
+constexpr int kWriteTilesMax = 1024;        // per-tile LDS words: (1 + waves) x tiles (images up to 512 x 512)
+
+// NT threads: NT / 64 waves rank the piece's pairs side by side, kBinChunk / NT consecutive entries per thread
+template <int NT>
+__global__ void __launch_bounds__(NT)
+bin_write_pairs_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
+                       const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ n_vis,
+                       const uint32_t* __restrict__ counts /*[V][nb][tiles]: block offsets*/,
+                       const uint32_t* __restrict__ tile_ranges, uint32_t* __restrict__ point_list,
+                       uint32_t capacity, int tile_bits) {
+  constexpr int NW = NT / 64, EPT = kBinChunk / NT, kPairBatches = kPairCap / NT;
+  extern __shared__ uint32_t dyn[];         // pos[tiles] | cnt[NW][tiles]
+  __shared__ uint2 s_rect[kBinChunk];
+  __shared__ uint32_t s_idx[kBinChunk];
+  __shared__ uint32_t s_pre[kBinChunk + 1];      // exclusive prefix of the entries' tile counts
+  __shared__ uint32_t s_pair[kPairCap];          // tile << 16 | entry (local)
+  __shared__ uint32_t s_scan[NW];
+  __shared__ uint32_t s_end;
+  const Dims m = make_dims(d);
+  uint32_t* const pos = dyn;
+  uint32_t* const cntw = dyn + m.tiles;
+  int v, b;
+  view_minor_block(b, v);
+  const uint32_t n = n_vis[v];
+  const uint32_t base = (uint32_t)b * kBinChunk;
+  if (base >= n) return;
+  const uint32_t cnt = n - base < (uint32_t)kBinChunk ? n - base : (uint32_t)kBinChunk;
+  const size_t vo = (size_t)v * m.G;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  // the thread's four consecutive entries; every load first
+  uint2 r4[EPT]; uint32_t i4[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const uint32_t e = (uint32_t)EPT * t + k;
+    const uint32_t ec = e < cnt ? e : 0u;
+    r4[k] = sorted_rect[vo + base + ec];
+    i4[k] = sorted_idx[vo + base + ec];
+  }
+  for (int i = t; i < m.tiles; i += NT)
+    pos[i] = tile_ranges[2 * ((size_t)v * m.tiles + i)] + counts[((size_t)v * m.nbin + b) * m.tiles + i];
+  uint32_t c4[EPT], mine = 0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const uint32_t e = (uint32_t)EPT * t + k;
+    const uint32_t xmin = r4[k].x & 0xFFFFu, ymin = r4[k].x >> 16, xmax = r4[k].y & 0xFFFFu, ymax = r4[k].y >> 16;
+    c4[k] = (e < cnt && xmax > xmin && ymax > ymin) ? (xmax - xmin) * (ymax - ymin) : 0u;
+    s_rect[e] = r4[k]; s_idx[e] = i4[k];
+    mine += c4[k];
+  }
+  // block exclusive scan of `mine` (wave scan by DPP-free shuffles, then the four wave totals)
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+  if (lane == 63) s_scan[w] = inc;
+  __syncthreads();
+  uint32_t wave_base = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) if (i < w) wave_base += s_scan[i];
+  uint32_t run = wave_base + inc - mine;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) { s_pre[EPT * t + k] = run; run += c4[k]; }
+  if (t == NT - 1) s_pre[kBinChunk] = run;
+  __syncthreads();
+  const uint32_t total = s_pre[kBinChunk];
+  const uint64_t lt = lanemask_lt();
+
+  uint32_t first = 0;                          // first entry of the piece
+  while (first < cnt) {
+    // the piece: entries [first, end) with at most kPairCap pairs (at least one entry: tiles <= kPairCap)
+    const uint32_t p0 = s_pre[first];
+    if (t == 0) s_end = cnt;
+    __syncthreads();
+    if (total - p0 > (uint32_t)kPairCap) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const uint32_t e = (uint32_t)EPT * t + k;
+        if (e >= first && e < cnt && s_pre[e + 1] - p0 > (uint32_t)kPairCap) atomicMin(&s_end, e);
+      }
+      __syncthreads();
+    }
+    const uint32_t end = s_end;
+    const uint32_t npairs = s_pre[end] - p0;
+    for (int i = t; i < NW * m.tiles; i += NT) cntw[i] = 0u;
+    // expand
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const uint32_t e = (uint32_t)EPT * t + k;
+      if (e >= first && e < end && c4[k] != 0u) {
+        const uint32_t xmin = r4[k].x & 0xFFFFu, ymin = r4[k].x >> 16, xmax = r4[k].y & 0xFFFFu, ymax = r4[k].y >> 16;
+        uint32_t q = s_pre[e] - p0;
+        for (uint32_t ty = ymin; ty < ymax; ++ty)
+          for (uint32_t tx = xmin; tx < xmax; ++tx) s_pair[q++] = ((ty * (uint32_t)m.gx + tx) << 16) | e;
+      }
+    }
+    __syncthreads();
+    // rank: wave w takes the pairs [w, w + 1) * per of the piece, 64 at a time, in order
+    const uint32_t per = ((npairs + (uint32_t)NT - 1u) / (uint32_t)NT) * 64u;
+    uint32_t pr[kPairBatches], rk[kPairBatches];
+#pragma unroll
+    for (int j = 0; j < kPairBatches; ++j) {
+      const uint32_t q = (uint32_t)w * per + (uint32_t)j * 64u + (uint32_t)lane;
+      const bool valid = (uint32_t)j * 64u < per && q < npairs;       // (first clause: wave-uniform)
+      pr[j] = valid ? s_pair[q] : 0xFFFFFFFFu;
+      rk[j] = 0u;
+      if ((uint32_t)j * 64u < per) {
+        const uint32_t tile = pr[j] >> 16;
+        uint64_t mask = __ballot(valid);
+        for (int bit = 0; bit < tile_bits; ++bit) {
+          const bool one = (tile >> bit) & 1u;
+          const uint64_t bal = __ballot(one);
+          mask &= one ? bal : ~bal;
+        }
+        if (valid) {
+          const uint32_t prefix = cntw[w * m.tiles + tile];
+          const uint32_t r = (uint32_t)__popcll(mask & lt);
+          rk[j] = prefix + r;
+          if (r == 0u) cntw[w * m.tiles + tile] = prefix + (uint32_t)__popcll(mask);
+        }
+        wave_lds_sync();
+      }
+    }
+    __syncthreads();
+    // per tile: the waves' counts -> starts; the tile's position moves on by the piece's total
+    for (int i = t; i < m.tiles; i += NT) {
+      uint32_t run_t = pos[i];
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) { const uint32_t c = cntw[ww * m.tiles + i]; cntw[ww * m.tiles + i] = run_t; run_t += c; }
+      pos[i] = run_t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPairBatches; ++j) {
+      if (pr[j] != 0xFFFFFFFFu) {
+        const uint32_t at = cntw[w * m.tiles + (pr[j] >> 16)] + rk[j];
+        if (at < capacity) point_list[at] = s_idx[pr[j] & 0xFFFFu];
+      }
+    }
+    __syncthreads();
+    first = end;
   }
 }
 
@@ -291,8 +446,25 @@ void launch_bin_write(const PsRasterDesc& d, const uint2* sorted_rect, const uin
   const Dims m = make_dims(d);
   dim3 grid(m.nbin, m.V);
   hipLaunchKernelGGL(bin_flag_kernel, dim3(1), dim3(64), 0, st, num_rendered, capacity);
-  hipLaunchKernelGGL(bin_kernel<true>, grid, dim3(256), 0, st, d, sorted_rect, sorted_idx, n_vis,
-                     counts, tile_ranges, point_list, capacity);
+  // PS_BIN_WRITE_WALK=1: the round-2 tile-parallel walk (A/B runs; also what larger tile grids take)
+  static const bool walk = [] { const char* e = getenv("PS_BIN_WRITE_WALK"); return e && e[0] == '1'; }();
+  if (!walk && m.tiles <= kWriteTilesMax && m.tiles <= kPairCap) {
+    int bits = 0;
+    while ((1 << bits) < m.tiles) ++bits;
+    static const int nt = [] { const char* e = getenv("PS_BIN_WRITE_THREADS"); return e ? atoi(e) : 512; }();
+    if (nt == 256)
+      hipLaunchKernelGGL(bin_write_pairs_kernel<256>, grid, dim3(256), 5 * m.tiles * sizeof(uint32_t), st, d,
+                         sorted_rect, sorted_idx, n_vis, counts, tile_ranges, point_list, capacity, bits);
+    else if (nt == 1024 && m.tiles <= 256)     // (static + dynamic LDS within 64 KB)
+      hipLaunchKernelGGL(bin_write_pairs_kernel<1024>, grid, dim3(1024), 17 * m.tiles * sizeof(uint32_t), st, d,
+                         sorted_rect, sorted_idx, n_vis, counts, tile_ranges, point_list, capacity, bits);
+    else
+      hipLaunchKernelGGL(bin_write_pairs_kernel<512>, grid, dim3(512), 9 * m.tiles * sizeof(uint32_t), st, d,
+                         sorted_rect, sorted_idx, n_vis, counts, tile_ranges, point_list, capacity, bits);
+  } else {
+    hipLaunchKernelGGL(bin_kernel<true>, grid, dim3(256), 0, st, d, sorted_rect, sorted_idx, n_vis,
+                       counts, tile_ranges, point_list, capacity);
+  }
 }
 
 }  // namespace ps
