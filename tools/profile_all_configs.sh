@@ -7,9 +7,9 @@
 # Round 5 additions: `comm` = the one-rank RCCL leg at configs[1] with the whole network's 0.48 GB of gradients
 # as payload in both launch modes (exposed communication per step), `connected` = the bench line with the
 # connected-step probe.
-# usage: tools/profile_all_configs.sh [tag, default r5] [what: "tests c2 c4 c5 scenes comm connected", default all]
+# usage: tools/profile_all_configs.sh [tag, default r6] [what: "tests c2 c4 c5 scenes comm connected", default all]
 cd "$(dirname "$0")/.."
-tag=${1:-r5}; what=${2:-"tests c2 c4 c5 scenes comm connected"}
+tag=${1:-r6}; what=${2:-"tests c2 c4 c5 scenes comm connected"}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 has() { case " $what " in *" $1 "*) return 0;; esac; return 1; }
