@@ -354,6 +354,9 @@ def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
         # per pixel (quadrant, lane) of a tile whose list the backward walks as two tasks: T after the
         # first half and the colour composited behind it over that T
         checkpoint=view(lay.checkpoint, V * tiles * 256 * 16, torch.float32, (V, tiles, 4, 64, 4)),
+        # which 4x4-pixel cells a visible pair can reach with alpha >= alpha_min (csrc/cell_window.h): small
+        # window = (mask lo, mask hi, anchor cx | cy << 16, 0), large footprint = (cx0 | cx1 << 16, cy0 | cy1 << 16, -, 1)
+        cell_windows=view(lay.cell_windows, N * 16, torch.int32, (V, G, 4)),
     )
 
 

@@ -21,6 +21,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _probe(nproc, backend, steps):
     env = dict(os.environ, PIXELSPLAT_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -30,7 +37,7 @@ def _probe(nproc, backend, steps):
         cmd = [sys.executable, os.path.join(ROOT, "tests", "_ddp_probe.py"), "--steps", str(steps)]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", "29731",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "tests", "_ddp_probe.py"), "--steps", str(steps)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-4000:]

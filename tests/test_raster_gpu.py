@@ -584,3 +584,88 @@ def test_fused_preprocess_ragged_sizes(gpu_device, n_scenes, vps, n_g):
         for leaf, key in zip(leaves, ("means", "cov", "sh", "op")):
             _grad_close(leaf.grad[s].cpu().numpy(), ref[key], f"{key} scene {s}")
     assert n_vis > 0.2 * V * n_g, "scene not exercised: almost nothing visible"
+
+
+def _window_cells(win, cells_x, cells_y):
+    """The set of image cells (cy * cells_x + cx) a cell window (csrc/cell_window.h) marks."""
+    x, y, z, w = (int(t) & 0xFFFFFFFF for t in win)
+    s16 = lambda u: ((u & 0xFFFF) ^ 0x8000) - 0x8000
+    out = set()
+    if w != 0:                                   # large footprint: inclusive cell ranges
+        cx0, cx1, cy0, cy1 = s16(x), s16(x >> 16), s16(y), s16(y >> 16)
+        for cy in range(max(cy0, 0), min(cy1, cells_y - 1) + 1):
+            for cx in range(max(cx0, 0), min(cx1, cells_x - 1) + 1):
+                out.add(cy * cells_x + cx)
+        return out
+    ax, ay = s16(z), s16(z >> 16)
+    mask = x | (y << 32)
+    for wy in range(8):
+        for wx in range(8):
+            if (mask >> (8 * wy + wx)) & 1:
+                cx, cy = ax + wx, ay + wy
+                if 0 <= cx < cells_x and 0 <= cy < cells_y:
+                    out.add(cy * cells_x + cx)
+    return out
+
+
+@pytest.mark.parametrize("scene,hw,stretch", [("survey", (64, 80), 0.0), ("survey", (48, 64), 40.0),
+                                              ("large", (64, 64), 8.0), ("opaque", (64, 64), 0.0)])
+def test_cell_windows_reach_every_contributing_cell(gpu_device, scene, hw, stretch):
+    """Round 6: the tile forward (csrc/raster_cells.hip) blends an entry only in the 4x4-pixel cells its CELL
+    WINDOW (written by the preprocess, csrc/cell_window.h) marks.  The images' parity with the oracle shows in
+    aggregate that nothing visible is culled; this test checks the window itself, pair by pair, against brute
+    force: every cell holding a pixel with power <= 0 and alpha = min(0.99, opacity exp(power)) >= 1/255 (float64,
+    the kernel's conic and centre) must be marked -- on ordinary splats, on needles (covariance + stretch x a random
+    rank-1 term: thin ellipses crossing many cells diagonally), on footprints over 8 cells (the range form) and on
+    opacities around the threshold.  Tightness is reported and loosely bounded: a window that marked everything
+    would pass the first check and make the forward slow."""
+    from pixelsplat_amd.decoder import render_cuda
+    from pixelsplat_amd.raster import state_views
+
+    dev = gpu_device
+    h, w = hw
+    ctx, tgt, g, _ = make_workload(1, hw, v_ctx=2, v_tgt=2, seed=7, scene=scene)
+    cov = g.covariances.clone()
+    if stretch > 0:
+        gen = torch.Generator().manual_seed(3)
+        d = torch.nn.functional.normalize(torch.randn(cov.shape[:2] + (3,), generator=gen), dim=-1)
+        s = cov.diagonal(dim1=-2, dim2=-1).mean(-1)                       # the splat's own scale
+        cov = cov + stretch * s[..., None, None] * d[..., :, None] * d[..., None, :]
+    op = g.opacities.clone()
+    op[:, ::7] = 1.02 / 255.0                                             # around the alpha threshold
+    op[:, 3::7] = 0.9 / 255.0                                             # below it: reaches nothing
+    V = tgt.near.numel()
+    img, aux = render_cuda(tgt.extrinsics.reshape(V, 4, 4).to(dev), tgt.intrinsics.reshape(V, 3, 3).to(dev),
+                           tgt.near.reshape(V).to(dev), tgt.far.reshape(V).to(dev), hw,
+                           torch.zeros((V, 3), device=dev), g.means.to(dev), cov.to(dev), g.harmonics.to(dev),
+                           op.to(dev), views_per_scene=V, return_aux=True)
+    sv = state_views(aux["cfg"], aux["state"], aux["layout"])
+    rec = sv["records"].cpu().numpy().astype(np.float64)
+    win = sv["cell_windows"].cpu().numpy()
+    radii = aux["radii"].cpu().numpy().reshape(V, -1)
+    cells_x, cells_y = (w + 3) // 4, (h + 3) // 4
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    cell_of = ((ys // 4) * cells_x + xs // 4).astype(np.int64)
+    n_pairs = reached_total = marked_total = big = 0
+    for v in range(V):
+        vis = np.flatnonzero(radii[v] > 0)
+        rng = np.random.default_rng(v)
+        for gi in rng.choice(vis, size=min(1500, vis.size), replace=False):
+            px, py, a, b, c, o = rec[v, gi, :6]
+            dx, dy = px - xs, py - ys
+            power = -0.5 * (a * dx * dx + c * dy * dy) - b * dx * dy
+            alpha = np.minimum(0.99, o * np.exp(np.minimum(power, 0.0)))
+            hit = (power <= 0) & (alpha >= (1.0 / 255.0) * (1 + 1e-5))      # (clear of the fp32 threshold noise)
+            reached = set(np.unique(cell_of[hit]).tolist())
+            marked = _window_cells(win[v, gi], cells_x, cells_y)
+            missing = reached - marked
+            assert not missing, (f"view {v} gaussian {gi}: cells {sorted(missing)[:6]} hold contributing pixels "
+                                 f"but the window {win[v, gi].tolist()} does not mark them")
+            n_pairs += 1
+            reached_total += len(reached)
+            marked_total += len(marked)
+            big += int(win[v, gi][3] != 0)
+    assert n_pairs > 500 and reached_total > 0
+    print(f"\n{scene} {hw} stretch {stretch}: {n_pairs} pairs ({big} in range form), cells reached {reached_total}, "
+          f"marked {marked_total} ({marked_total / reached_total:.2f} x)")
+    assert marked_total <= 2.5 * reached_total + 4 * n_pairs        # conservative, not indiscriminate
