@@ -258,23 +258,62 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     wave_lds_sync();
   }
   __syncthreads();
+  // Round 6: the block's keys leave through LDS in block-sorted order.  Scattered straight from the ranking
+  // lanes, every 4-byte store went to a (block, digit) run of its own -- ~8 keys per run with 512 digits -- and
+  // the memory side wrote 245 MB for 35 MB of keys and values per pass (WRITE_SIZE, profiles/r6_c2_pmc_traffic.json:
+  // 3.7 TB/s of partial sectors, which is what a pass waited for).  Now: per digit the waves' local offsets and the
+  // block total, an exclusive scan over the digits, every item staged at its position in the block's sorted order,
+  // and thread t writes staged items t, t + 1024, ...: a run of one digit leaves as consecutive lanes of one store.
+  __shared__ uint32_t s_key[kSortChunk];
+  __shared__ uint32_t s_val[kSortChunk];
+  __shared__ uint16_t s_dig[kSortChunk];
+  __shared__ uint32_t s_lstart[kDigits];      // first block-sorted position of the digit
+  __shared__ uint32_t s_gbase[kDigits];       // global position of the digit's first key of this block
+  __shared__ uint32_t s_scan[kDigits];
+  uint32_t dtot = 0;
   if (t < kDigits) {
-    uint32_t b = digit_base;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { const uint32_t c = cnt[i][t]; cnt[i][t] = b; b += c; }
+    for (int i = 0; i < NW; ++i) { const uint32_t c = cnt[i][t]; cnt[i][t] = dtot; dtot += c; }   // offset inside the digit
+    s_gbase[t] = digit_base;
+    s_scan[t] = dtot;
   }
   __syncthreads();
-  uint32_t* const vout = (MAYBE_LAST && last) ? sorted_idx : vals_out;
+  uint32_t dx = dtot;
+  for (int off = 1; off < kDigits; off <<= 1) {
+    const uint32_t y = (t < kDigits && t >= off) ? s_scan[t - off] : 0u;
+    __syncthreads();
+    if (t < kDigits) { dx += y; s_scan[t] = dx; }
+    __syncthreads();
+  }
+  if (t < kDigits) s_lstart[t] = dx - dtot;
+  const uint32_t n_valid = s_scan[kDigits - 1];          // (read after the last barrier of the scan)
+  __syncthreads();
+  const bool is_last = MAYBE_LAST && last;
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     if (rank[i] != kCulledKey) {
       const uint32_t dg = digit_of(key[i], kmin, shift);
-      const uint32_t pos = cnt[w][dg] + rank[i];
-      if (!(MAYBE_LAST && last)) keys_out[vo + pos] = key[i];   // nobody reads the keys after the last pass
-      vout[vo + pos] = val[i];
-      if (MAYBE_LAST) { if (last) sorted_rect[vo + pos] = rc[i]; }
+      const uint32_t in_digit = cnt[w][dg] + rank[i];
+      const uint32_t lp = s_lstart[dg] + in_digit;
+      s_key[lp] = key[i]; s_val[lp] = val[i]; s_dig[lp] = (uint16_t)dg;
+      if (MAYBE_LAST) { if (is_last) sorted_rect[vo + s_gbase[dg] + in_digit] = rc[i]; }   // (8 bytes: from the lane that gathered it)
     }
   }
+  __syncthreads();
+  uint32_t* const vout = is_last ? sorted_idx : vals_out;
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const uint32_t lp = (uint32_t)t + (uint32_t)i * kSortThreads;
+    if (lp < n_valid) {
+      const uint32_t dg = s_dig[lp];
+      const uint32_t pos = s_gbase[dg] + (lp - s_lstart[dg]);
+      if (!is_last) keys_out[vo + pos] = s_key[lp];     // nobody reads the keys after the last pass
+      vout[vo + pos] = s_val[lp];
+    }
+  }
+  // (the last pass's 8-byte rects still leave from the lanes that gathered them: gathering them HERE, by the lanes
+  //  that write the runs, exposes the gather's latency at the end of the block -- 0.32 instead of 0.277 ms for the
+  //  sort, profiles/r6_ab_sort.txt)
 }
 
 void launch_sort(const PsRasterDesc& d, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
