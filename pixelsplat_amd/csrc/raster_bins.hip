@@ -104,7 +104,6 @@ bin_write_pairs_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
                        uint32_t capacity, int tile_bits) {
   constexpr int NW = NT / 64, EPT = kBinChunk / NT, kPairBatches = kPairCap / NT;
   extern __shared__ uint32_t dyn[];         // pos[tiles] | cnt[NW][tiles]
-  __shared__ uint2 s_rect[kBinChunk];
   __shared__ uint32_t s_idx[kBinChunk];
   __shared__ uint32_t s_pre[kBinChunk + 1];      // exclusive prefix of the entries' tile counts
   __shared__ uint32_t s_pair[kPairCap];          // tile << 16 | entry (local)
@@ -138,7 +137,7 @@ bin_write_pairs_kernel(PsRasterDesc d, const uint2* __restrict__ sorted_rect,
     const uint32_t e = (uint32_t)EPT * t + k;
     const uint32_t xmin = r4[k].x & 0xFFFFu, ymin = r4[k].x >> 16, xmax = r4[k].y & 0xFFFFu, ymax = r4[k].y >> 16;
     c4[k] = (e < cnt && xmax > xmin && ymax > ymin) ? (xmax - xmin) * (ymax - ymin) : 0u;
-    s_rect[e] = r4[k]; s_idx[e] = i4[k];
+    s_idx[e] = i4[k];
     mine += c4[k];
   }
   // block exclusive scan of `mine` (wave scan by DPP-free shuffles, then the four wave totals)
