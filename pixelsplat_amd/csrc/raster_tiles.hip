@@ -50,15 +50,20 @@ constexpr float kLog2e = 1.4426950408889634f;
 struct WaveLds {
   float4 rec[kQB][3];               // {gx,gy,A,B} {C,opacity,r,g} {b,list index,quad mask,id}
 };
-// The backward's nine per-entry sums stop one DPP step early -- 8-lane partial sums, 24 floats per
-// entry -- and are staged in LDS; the lane that finalises the entry adds the halves.  Per
-// contributing entry 9 DPP adds instead of 14 and no flag traffic (the "entry contributed" bits stay
-// in an SGPR), at the price of finalising every 32 instead of every 64 entries: tiles_backward
-// 1.81 -> 1.75 ms at BASELINE configs[1] (profiles/r3_variants_ab.txt; round 2 had the full 64-lane sums
-// and a per-entry flag in LDS).
-constexpr int kStage = 32;              // entries per finalisation batch
-struct WaveLdsBwd : WaveLds {
-  float stage[kStage][3][8];            // per entry: r1, r2, s_b as 8-lane partial sums
+// The backward's nine per-entry sums leave the VALU after the two lane-swap folds (round 6): eight of them are
+// then the four 16-lane rows of two registers (16 partial sums per value), the ninth is still one value per lane,
+// and all 64 lanes stage the three registers in LDS (768 bytes per entry).  The LDS pipe does the rest of the
+// transposition: eight lanes finalise an entry, each reads the 16 partials of ONE value (+ 8 of the ninth's 64)
+// as 16-byte words and adds them -- 64 busy lanes per batch of 8 entries, where rounds 3 - 5 spent 9 DPP adds per
+// contributing entry to get down to 8-lane partials and finalised with one lane per entry.  The stage is paid
+// for with the ring: 64 records, refilled when it has run dry and blended down to the last entry after every
+// refine (9216 bytes per wave as before = 16 waves per CU).
+constexpr int kBwdBatch = 64;           // list entries per refine
+constexpr int kBwdQB = 64;              // ring capacity = one refine
+constexpr int kStage = 8;               // entries per finalisation batch (8 lanes each)
+struct WaveLdsBwd {
+  float4 rec[kBwdQB][3];                // {gx,gy,A,B} {C,opacity,r,g} {b,list index,quad mask,id}
+  float stage[kStage][3][kWave];        // per entry: r1, r2 (rows of 16 partials), the ninth sum (64 partials)
 };
 
 __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
@@ -431,43 +436,37 @@ void launch_tiles_forward(const PsRasterDesc& d, const float* records,
 // ------------------------------------------------------------------------------------
 // backward: walk the tile's bin back to front from the last contributor
 // ------------------------------------------------------------------------------------
-// Nine wave64 sums with the gfx950 lane-swap instructions.  v_permlane32_swap exchanges the
-// upper half of one register with the lower half of another, so ONE swap + ONE add folds two
-// values from 64 to 32 lanes each (a butterfly step that halves the number of live
-// registers); v_permlane16_swap does the same between odd and even rows of 16.  Eight values
-// end up as the four 16-lane rows of two registers, reduced by four DPP row_shr adds each:
-//   r1 rows = [a, c, b, d], r2 rows = [e, g, f, h]  (row total in lane 15 of the row),
-// and the ninth value takes the plain DPP chain (total in lane 63).  26 instructions instead
-// of 54, and the totals are stored from four lanes at once.
-__device__ __forceinline__ float fold32(float x, float y) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);       // [x_lo + x_hi | y_lo + y_hi]
+// Eight of the nine wave64 sums with the gfx950 lane-swap instructions.  v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, so ONE swap + ONE add folds two values from
+// 64 to 32 lanes each (a butterfly step that halves the number of live registers); v_permlane16_swap does
+// the same between odd and even rows of 16.  The values come as the four register PAIRS the blend loop
+// accumulates them in -- (a, e) (c, g) (b, f) (d, h) -- and the swaps are taken pair against pair, so that
+// both adds of a level are ONE packed add on registers that are pairs already:
+//   level 1:  swap32(a, c) swap32(e, g) -> (a, e) + (c, g) = U = ([a | c], [e | g])     (32-lane halves)
+//             swap32(b, d) swap32(f, h) -> (b, f) + (d, h) = W = ([b | d], [f | h])
+//   level 2:  swap16(U.x, W.x) swap16(U.y, W.y) -> U + W = (rows [a, b, c, d], rows [e, f, g, h])
+// 6 swaps + 3 packed adds; every 16-lane row of the result holds 16 partial sums of one value.
+__device__ __forceinline__ f32x2 wave_fold8_rows(f32x2 ae, f32x2 cg, f32x2 bf, f32x2 dh) {
+  auto swap32 = [](float x, float y) {
+    return __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  };
+  auto swap16 = [](float x, float y) {
+    return __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  };
+  const auto s0 = swap32(ae.x, cg.x), s1 = swap32(ae.y, cg.y);
+  const f32x2 U = f32x2{__uint_as_float(s0[0]), __uint_as_float(s1[0])} +
+                  f32x2{__uint_as_float(s0[1]), __uint_as_float(s1[1])};
+  const auto s2 = swap32(bf.x, dh.x), s3 = swap32(bf.y, dh.y);
+  const f32x2 W = f32x2{__uint_as_float(s2[0]), __uint_as_float(s3[0])} +
+                  f32x2{__uint_as_float(s2[1]), __uint_as_float(s3[1])};
+  const auto t0 = swap16(U.x, W.x), t1 = swap16(U.y, W.y);
+  return f32x2{__uint_as_float(t0[0]), __uint_as_float(t1[0])} +
+         f32x2{__uint_as_float(t0[1]), __uint_as_float(t1[1])};
 }
-__device__ __forceinline__ float fold16(float x, float y) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);       // rows [x0+x1, y0+y1, x2+x3, y2+y3]
-}
-// the nine sums down to 8-lane partials: r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]
-// (as in wave_sum9_rows), i = s_b; afterwards lanes 7 and 15 of every 16-lane row hold the sums of
-// lanes 0-7 and 8-15 of that row
-__device__ __forceinline__ void wave_sum9_partials(float a, float b, float c, float d, float e,
-                                                   float f, float g, float h, float& i, float& r1,
-                                                   float& r2) {
-  r1 = fold16(fold32(a, b), fold32(c, d));
-  r2 = fold16(fold32(e, f), fold32(g, h));
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-      "s_nop 1\n"
-      : "+v"(r1), "+v"(r2), "+v"(i));
+// DPP moves inside the 8 lanes that finalise one entry (quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, true));
 }
 
 // The loop is the last of the round-2 A/B series (profiles/r2_tiles_variants_ab.txt: 2.14 -> 1.82 ms at
@@ -584,6 +583,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
   const uint64_t lt = lanemask_lt();
   uint32_t b_head = 0, b_tail = 0;
+  // finalisation (stage_batch): entry and value of this lane, float offset of the value's 16 partials in the stage
+  // (stage rows 0..7 = Mx, s_r, Mxx, s_b, My, s_g, Mxy, Myy  ->  row of fp = 0, 4, 2, 6, 7, 3, 1, 5)
+  const uint32_t fe = (uint32_t)lane >> 3, fp = (uint32_t)lane & 7u;
+  const uint32_t f_voff = ((0x51376240u >> (4u * fp)) & 15u) * 16u;
   // the per-pixel colour state as 2-vectors (channels 0,1 | channel 2) so that the packed
   // instructions take their operands in place (the auto-vectoriser packs the scalar form too, but
   // assembles the register pairs with ~5 v_mov per pixel and entry)
@@ -641,7 +644,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       }
     }
     if (keep) {
-      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kQB - 1);
+      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kBwdQB - 1);
       lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
     }
     b_tail = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask));   // (wave-uniform: say so)
@@ -661,11 +664,11 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       const float o = q1.y, c0 = q1.z, c1 = q1.w, c2 = q2.x;
       const uint32_t hidx = __float_as_uint(q2.y);
       const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-      float Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
-      float s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
-      bool any = false;
+      // the nine sums as the blend loop's register pairs: (Mx, My) (Mxx, Mxy) (s_r, s_g) (s_b, Myy) + s_op
+      f32x2 M1 = {0.f, 0.f}, M2 = {0.f, 0.f}, s_rg = {0.f, 0.f}, sbM = {0.f, 0.f};
+      float s_op = 0.f;
+      uint64_t any = 0ull;      // lanes with a contributing pixel, as the compares' own masks (scalar ORs)
       {
-        f32x2 M1 = {0.f, 0.f}, M2 = {0.f, 0.f}, s_rg = {0.f, 0.f};   // (Mx, My) (Mxx, Mxy) (s_r, s_g)
         const f32x2 c01 = f32x2{c0, c1};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -693,7 +696,6 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             dL_dalpha = fmaf(Tfb[k], rcp, dL_dalpha);       // -T_final/(1-alpha) * bg.dL/dC
             const float dch = ale * Tn;
             s_rg = f32x2{dch, dch} * g01[k] + s_rg;
-            s_b = fmaf(dch, g2[k], s_b);
             float q;                                        // opacity * G * dL/dalpha = G * dL/dG
             if (FAST) {
               q = ale * dL_dalpha;
@@ -706,23 +708,20 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const f32x2 qxy = f32x2{q, q} * dd;             // (q dx, q dy)
             M1 += qxy;
             M2 = f32x2{qxy.x, qxy.x} * dd + M2;             // (Mxx, Mxy) += q dx (dx, dy)
-            Myy = fmaf(qxy.y, dd.y, Myy);
+            sbM = f32x2{dch, qxy.y} * f32x2{g2[k], dd.y} + sbM;   // (s_b, Myy) += (dch g2, q dy dy)
             T[k] = Tn;
             acc01[k] = f32x2{ale, ale} * d01 + acc01[k];    // alpha c + (1 - alpha) acc
             acc2[k] = fmaf(ale, d2, acc2[k]);
-            any |= ok;
+            any |= __builtin_amdgcn_ballot_w64(ok);
           }
         }
-        Mx = M1.x; My = M1.y; Mxx = M2.x; Mxy = M2.y; s_r = s_rg.x; s_g = s_rg.y;
       }
-      if (__any(any)) {
+      if (any != 0ull) {
         // moments about the Gaussian centre: Mx = sum q dx, My = sum q dy, ...
-        float r1, r2;
-        wave_sum9_partials(Mx, My, Mxx, Mxy, Myy, s_op, s_r, s_g, s_b, r1, r2);
-        if ((lane & 7) == 7) {
-          float* st = &lds.stage[j][0][lane >> 3];
-          st[0] = r1; st[8] = r2; st[16] = s_b;
-        }
+        // r.x rows = [Mx, s_r, Mxx, s_b], r.y rows = [My, s_g, Mxy, Myy]; all 64 lanes stage their partials
+        const f32x2 r = wave_fold8_rows(M1, M2, s_rg, sbM);
+        float* st = &lds.stage[j][0][lane];
+        st[0] = r.x; st[kWave] = r.y; st[2 * kWave] = s_op;
         hitbits |= 1u << j;                 // wave-uniform: stays in an SGPR
       }
   };
@@ -735,55 +734,68 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     constexpr bool FAST = decltype(fast_tag)::value;
     hitbits = 0;
     {
-      uint32_t slot = (b_head + base) & (kQB - 1);
+      uint32_t slot = (b_head + base) & (kBwdQB - 1);
       float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
       for (uint32_t j = 0; j < cnt; j += 2) {
-        slot = (b_head + base + j + 1) & (kQB - 1);          // (stale beyond cnt: never processed)
+        slot = (b_head + base + j + 1) & (kBwdQB - 1);          // (stale beyond cnt: never processed)
         const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
         entry(fast_tag, j, a0, a1, a2);
         if (j + 1 >= cnt) break;
-        slot = (b_head + base + j + 2) & (kQB - 1);
+        slot = (b_head + base + j + 2) & (kBwdQB - 1);
         a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
         entry(fast_tag, j + 1, b0, b1, b2);
       }
     }
     wave_lds_sync();
-    if ((uint32_t)lane < cnt) {
-      const uint32_t slot = (b_head + base + lane) & (kQB - 1);
+    // eight lanes finalise entry fe: lane fp adds the 16 partials of ONE of the eight folded values and 8 of the
+    // ninth's 64, the ninth is then summed over the eight lanes; lane fp produces float fp of the 9-float result
+    //   fp:     0    1    2    3    4    5    6    7
+    //   value:  Mx   My   Mxx  Mxy  Myy  s_b  s_r  s_g      (stage rows: r1 = [Mx, s_r, Mxx, s_b], r2 = [My, s_g, Mxy, Myy])
+    //   result: o0   o1   o2   o3   o4   s_op s_r  s_g  + float 8 = s_b (from lane 5)
+    // private slot (always written: values or zeros), per-entry slot (deterministic mode), or atomics
+    if (fe < cnt) {
+      const uint32_t slot = (b_head + base + fe) & (kBwdQB - 1);
       const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
-      const float4* sp = reinterpret_cast<const float4*>(&lds.stage[lane][0][0]);
-      const float4 u0 = sp[0], u1 = sp[1], v0 = sp[2], v1 = sp[3], w0 = sp[4], w1 = sp[5];
-      const bool hit = (hitbits >> lane) & 1u;
-      // r1 rows = [Mx, Mxx, My, Mxy], r2 rows = [Myy, s_r, s_op, s_g]; a row = two 8-lane halves
-      const float Mx = u0.x + u0.y, Mxx = u0.z + u0.w, My = u1.x + u1.y, Mxy = u1.z + u1.w;
-      const float Myy = v0.x + v0.y, s_r = v0.z + v0.w, s_g = v1.z + v1.w;
-      float s_op = v1.x + v1.y;
-      if (FAST) s_op = s_op / q1.y;           // the fast form summed opacity * G dL/dalpha
-      const float s_b = ((w0.x + w0.y) + (w0.z + w0.w)) + ((w1.x + w1.y) + (w1.z + w1.w));
+      const float* sp = &lds.stage[fe][0][0];
+      // (the 16-byte words are visited in a lane-rotated order: the eight lanes of an entry -- and with them all
+      // 64 -- read eight different words of the 128-byte bank window at a time)
+      const float4* vp = reinterpret_cast<const float4*>(sp + f_voff);
+      const float4 u0 = vp[fp & 3u], u1 = vp[(fp + 1u) & 3u], u2 = vp[(fp + 2u) & 3u], u3 = vp[(fp + 3u) & 3u];
+      const float4* wp = reinterpret_cast<const float4*>(sp + 2 * kWave + fp * 8u);
+      const float4 w0 = wp[(fp >> 2) & 1u], w1 = wp[((fp >> 2) & 1u) ^ 1u];
+      const bool hit = (hitbits >> fe) & 1u;
+      const float4 us = (u0 + u1) + (u2 + u3);
+      const float own = (us.x + us.y) + (us.z + us.w);
+      const float4 ws = w0 + w1;
+      float s_op = (ws.x + ws.y) + (ws.z + ws.w);
+      s_op += dpp_mov<0xB1>(s_op);          // quad_perm [1,0,3,2]
+      s_op += dpp_mov<0x4E>(s_op);          // quad_perm [2,3,0,1]
+      s_op += dpp_mov<0x141>(s_op);         // row_half_mirror: the other quad of the eight
+      if (FAST) s_op *= __builtin_amdgcn_rcpf(q1.y);   // the fast form summed opacity * G dL/dalpha (rcp: 1 ulp)
+      const float other = dpp_mov<0xB1>(own);   // lanes 0 / 1: My / Mx
       const float cx = q0.z * (-2.f / kLog2e), cy = q0.w * (-1.f / kLog2e),
                   cz = q1.x * (-2.f / kLog2e);
-      const float o0 = (-cx * Mx - cy * My) * ddelx_dx, o1 = (-cz * My - cy * Mx) * ddely_dy;
-      const float o2 = -0.5f * Mxx, o3 = -0.5f * Mxy, o4 = -0.5f * Myy;
+      float out = fp == 0u ? (-cx * own - cy * other) * ddelx_dx : (-cz * own - cy * other) * ddely_dy;
+      out = fp >= 2u ? -0.5f * own : out;
+      out = fp >= 6u ? own : out;
+      out = fp == 5u ? s_op : out;
+      const uint32_t i2 = 8u + ((fp - 5u) & 7u);      // float 8 (s_b) from lane 5, the slot's padding from its neighbours
       if (__float_as_uint(q2.z) & 16u) {
-        // private slot of this (Gaussian, tile): plain 16-byte stores, summed later in a fixed
-        // order by the geometry backward (no atomics, deterministic)
-        float4* tg = slots + (size_t)__float_as_uint(q2.w) * kSlotVec;
-        tg[0] = hit ? make_float4(o0, o1, o2, o3) : make_float4(0.f, 0.f, 0.f, 0.f);
-        tg[1] = hit ? make_float4(o4, s_op, s_r, s_g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        tg[2] = make_float4(hit ? s_b : 0.f, 0.f, 0.f, 0.f);
-        if (kSlotVec == 4) tg[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // private slot of this (Gaussian, tile): plain stores, summed later in a fixed order by the geometry
+        // backward (no atomics, deterministic)
+        float* tg = reinterpret_cast<float*>(slots + (size_t)__float_as_uint(q2.w) * kSlotVec);
+        tg[fp] = hit ? out : 0.f;
+        if (i2 < (uint32_t)kSlotFloats) tg[i2] = (hit && fp == 5u) ? own : 0.f;
       } else if (DET) {
         if (hit) {      // (entries that never get here keep the zeros the caller cleared the slots to)
-          float4* ds = det_slots + ((size_t)l_start + (__float_as_uint(q2.y) - 1u)) * kSlotVec;
-          ds[0] = make_float4(o0, o1, o2, o3);
-          ds[1] = make_float4(o4, s_op, s_r, s_g);
-          ds[2] = make_float4(s_b, 0.f, 0.f, 0.f);
+          float* ds = reinterpret_cast<float*>(det_slots + ((size_t)l_start + (__float_as_uint(q2.y) - 1u)) * kSlotVec);
+          ds[fp] = out;
+          if (i2 < (uint32_t)kSlotFloats) ds[i2] = fp == 5u ? own : 0.f;
         }
       } else if (hit) {
         float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
-        atomicAdd(ga + 0, o0); atomicAdd(ga + 1, o1); atomicAdd(ga + 2, o2);
-        atomicAdd(ga + 3, o3); atomicAdd(ga + 4, o4); atomicAdd(ga + 5, s_op);
-        atomicAdd(ga + 6, s_r); atomicAdd(ga + 7, s_g); atomicAdd(ga + 8, s_b);
+        atomicAdd(ga + fp, out);
+        if (fp == 5u) atomicAdd(ga + 8, own);
       }
     }
     wave_lds_sync();     // the staging rows are rewritten by the next batch
@@ -801,7 +813,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     for (uint32_t base = 0; base < m; base += kStage) {
       const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
       // the batch's first entry has its highest list index (the walk runs back to front)
-      const uint32_t slot = (b_head + base) & (kQB - 1);
+      const uint32_t slot = (b_head + base) & (kBwdQB - 1);
       const uint32_t top_h =
           __builtin_amdgcn_readfirstlane(__float_as_uint(lds.rec[slot][2].y));
       // short form: every entry from here to the ring's tail is plain and inside every pixel's walk
@@ -812,15 +824,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   };
 
   for (uint32_t top = hi; top > lo;) {
-    const uint32_t m = top - lo < (uint32_t)kBatch ? top - lo : (uint32_t)kBatch;
-    refine(top, m);
-    // full batches while the list lasts, then whatever is left (ONE call site)
-    const bool last_batch = top - m == lo;
-    for (;;) {
-      const uint32_t have = __builtin_amdgcn_readfirstlane(b_tail - b_head);
-      if (!(have >= (uint32_t)kBatch || (last_batch && have != 0u))) break;
-      blend(have < (uint32_t)kBatch ? have : (uint32_t)kBatch);
-    }
+    const uint32_t m = top - lo < (uint32_t)kBwdBatch ? top - lo : (uint32_t)kBwdBatch;
+    refine(top, m);           // (the ring is empty here: it holds exactly one refine)
+    const uint32_t have = __builtin_amdgcn_readfirstlane(b_tail - b_head);
+    if (have != 0u) blend(have);
     top -= m;
   }
 }

@@ -10,12 +10,11 @@ python - "$f" <<'PY' > gpurun_out/${tag}_timeline.txt
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# last occurrence of tiles_backward marks the end of the last step; print the 140 kernels before it
-idx = max(i for i, r in enumerate(rows) if 'tiles_backward' in r['Kernel_Name'])
-lo = max(0, idx - 120)
+# the whole last step: from the last camera_setup (the first kernel of (B)) to the end of the trace, (A) included
+lo = max(i for i, r in enumerate(rows) if 'camera_setup' in r['Kernel_Name'])
 t0 = int(rows[lo]['Start_Timestamp'])
-for r in rows[lo:idx + 12]:
+for r in rows[lo:]:
     s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
     print(f"{s/1e3:9.1f} {(e-s)/1e3:8.1f} us  q{r.get('Queue_Id','?'):>3s}  {r['Kernel_Name'][:70]}")
 PY
-tail -n 75 gpurun_out/${tag}_timeline.txt
+tail -n 40 gpurun_out/${tag}_timeline.txt
