@@ -137,4 +137,32 @@ __device__ __forceinline__ uint32_t quad_cell_mask(uint4 w, int qcx, int qcy) {
   return w.w != 0u ? big_mask : small_mask;
 }
 
+// The 4-bit mask of the 8x8 QUADRANTS of tile (tx, ty) (bit k: x half = k & 1, y half = k >> 1; a quadrant = 2x2
+// cells) out of a pair's cell window -- the tile backward's cull (raster_tiles.hip: one wave walks the whole
+// tile, a quadrant per evaluation).  Small window: the four window rows of the tile are one 64-bit shift, the
+// two cell columns of a half are a byte mask replicated over the rows of a half.
+__device__ __forceinline__ uint32_t tile_quad_mask(uint4 w, int tx, int ty) {
+  const int tcx = 4 * tx, tcy = 4 * ty;
+  uint32_t small_mask;
+  {
+    int ox = tcx - cw_lo(w.z), oy = tcy - cw_hi(w.z);
+    const bool rows_ok = oy > -4 && oy < 8;
+    ox = ox < -4 ? -4 : (ox > 8 ? 8 : ox);            // (outside -3 .. 7 both column masks are empty)
+    oy = oy < -3 ? -3 : (oy > 7 ? 7 : oy);
+    const uint64_t W = (uint64_t)w.x | ((uint64_t)w.y << 32);
+    const uint32_t R = rows_ok ? (uint32_t)(oy >= 0 ? W >> (8 * oy) : W << (-8 * oy)) : 0u;   // byte j = window row oy + j
+    const uint32_t cl = ((0x3u << (ox + 4)) >> 4) & 0xFFu, cr = ((0xCu << (ox + 4)) >> 4) & 0xFFu;
+    const uint32_t L = R & (cl * 0x01010101u), Rr = R & (cr * 0x01010101u);
+    small_mask = ((L & 0xFFFFu) ? 1u : 0u) | ((Rr & 0xFFFFu) ? 2u : 0u) | ((L >> 16) ? 4u : 0u) | ((Rr >> 16) ? 8u : 0u);
+  }
+  uint32_t big_mask;
+  {
+    const int i0 = cw_lo(w.x) - tcx, i1 = cw_hi(w.x) - tcx, j0 = cw_lo(w.y) - tcy, j1 = cw_hi(w.y) - tcy;
+    const uint32_t cols = ((i0 <= 1 && i1 >= 0) ? 1u : 0u) | ((i0 <= 3 && i1 >= 2) ? 2u : 0u);
+    const uint32_t rows = ((j0 <= 1 && j1 >= 0) ? 3u : 0u) | ((j0 <= 3 && j1 >= 2) ? 12u : 0u);
+    big_mask = (cols | (cols << 2)) & rows;
+  }
+  return w.w != 0u ? big_mask : small_mask;
+}
+
 }  // namespace ps

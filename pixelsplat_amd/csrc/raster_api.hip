@@ -322,7 +322,7 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
   }
   {
     Scope sc(G_TILES_BWD, st);
-    launch_tiles_backward(*d, records, task_order, tile_ranges, point_list, capacity, view_params,
+    launch_tiles_backward(*d, records, (const uint4*)(sb + L.cell_windows), task_order, tile_ranges, point_list, capacity, view_params,
                           final_T, n_contrib, checkpoint, tile_end, dL_dcolor, grad2d, tile_grads,
                           det_slots, st);
     if (deterministic)

@@ -158,7 +158,7 @@ void launch_tiles_forward_rows(const PsRasterDesc& d, const float* records, cons
 void launch_backward_task_order(const PsRasterDesc& d, const uint32_t* tile_ranges,
                                 const uint32_t* tile_end, uint32_t capacity, uint32_t* task_order,
                                 hipStream_t st);
-void launch_tiles_backward(const PsRasterDesc& d, const float* records,
+void launch_tiles_backward(const PsRasterDesc& d, const float* records, const uint4* cell_windows,
                            const uint32_t* task_order, const uint32_t* tile_ranges,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,

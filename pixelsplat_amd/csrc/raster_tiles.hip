@@ -22,6 +22,7 @@
 // Replaces renderCUDA fwd/bwd of the external rasterizer (call site
 // /root/reference/src/model/decoder/cuda_splatting.py:117-124).
 #include "raster_common.h"
+#include "cell_window.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -481,6 +482,7 @@ __device__ __forceinline__ float dpp_mov(float x) {
 template <bool DET>
 __global__ void __launch_bounds__(kWavesPerBlockBwd* kWave, 4)
 tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
+                      const uint4* __restrict__ cell_windows,
                       const uint32_t* __restrict__ task_order,
                       const uint32_t* __restrict__ tile_ranges,
                       const uint32_t* __restrict__ point_list, uint32_t capacity,
@@ -517,6 +519,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const uint32_t tx = t % gx, ty = t / gx;
   const size_t vo = (size_t)v * G;
   const float* recs = records + vo * kRecFloats;
+  const uint4* wins = cell_windows + vo;
   float* gacc = grad2d + vo * kGradFloats;
   uint32_t l_start = tile_ranges[2 * (size_t)tile_global];
   if (l_start > capacity) l_start = capacity;
@@ -612,8 +615,12 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       const uint32_t id = id_now;
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
       const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
+      const uint4 win = wins[id];
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
-      const uint32_t qm = quadrant_mask(r0.x, r0.y, A, B, Cq, r1.y, alpha_min, x0, y0);
+      // which quadrants the entry can reach with alpha >= alpha_min: read off the pair's cell window (the
+      // preprocess computed it once per pair, cell_window.h; rounds 2 - 5 minimised the quadratic form over
+      // each quadrant's box here, per list entry: nine divisions, 2/3 of the refine's instructions)
+      const uint32_t qm = tile_quad_mask(win, (int)tx, (int)ty);
       keep = qm != 0u;
       q0 = make_float4(r0.x, r0.y, A, B);
       q1 = make_float4(Cq, r1.y, r2.x, r2.y);
@@ -708,7 +715,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const f32x2 qxy = f32x2{q, q} * dd;             // (q dx, q dy)
             M1 += qxy;
             M2 = f32x2{qxy.x, qxy.x} * dd + M2;             // (Mxx, Mxy) += q dx (dx, dy)
-            sbM = f32x2{dch, qxy.y} * f32x2{g2[k], dd.y} + sbM;   // (s_b, Myy) += (dch g2, q dy dy)
+            // (s_b, Myy) += (dch g2, q dy dy) as TWO scalar FMAs on the halves of a pair: packed, the two factor
+            // pairs would have to be assembled with a v_mov each, per evaluation
+            asm("v_fmac_f32 %0, %1, %2" : "+v"(sbM.x) : "v"(dch), "v"(g2[k]));
+            asm("v_fmac_f32 %0, %1, %2" : "+v"(sbM.y) : "v"(qxy.y), "v"(dd.y));
             T[k] = Tn;
             acc01[k] = f32x2{ale, ale} * d01 + acc01[k];    // alpha c + (1 - alpha) acc
             acc2[k] = fmaf(ale, d2, acc2[k]);
@@ -912,7 +922,7 @@ void launch_backward_task_order(const PsRasterDesc& d, const uint32_t* tile_rang
                      tile_end, capacity, task_order);
 }
 
-void launch_tiles_backward(const PsRasterDesc& d, const float* records,
+void launch_tiles_backward(const PsRasterDesc& d, const float* records, const uint4* cell_windows,
                            const uint32_t* task_order, const uint32_t* tile_ranges,
                            const uint32_t* point_list,
                            uint32_t capacity, const float* view_params, const float* final_T,
@@ -923,11 +933,11 @@ void launch_tiles_backward(const PsRasterDesc& d, const float* records,
   const int total = 2 * m.V * m.tiles;
   dim3 grid((total + kWavesPerBlockBwd - 1) / kWavesPerBlockBwd), block(kWavesPerBlockBwd * kWave);
   if (det_slots != nullptr)
-    hipLaunchKernelGGL(tiles_backward_kernel<true>, grid, block, 0, st, d, records, task_order, tile_ranges,
+    hipLaunchKernelGGL(tiles_backward_kernel<true>, grid, block, 0, st, d, records, cell_windows, task_order, tile_ranges,
                        point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
                        dL_dcolor, grad2d, tile_grads, reinterpret_cast<float4*>(det_slots));
   else
-    hipLaunchKernelGGL(tiles_backward_kernel<false>, grid, block, 0, st, d, records, task_order, tile_ranges,
+    hipLaunchKernelGGL(tiles_backward_kernel<false>, grid, block, 0, st, d, records, cell_windows, task_order, tile_ranges,
                        point_list, capacity, view_params, final_T, n_contrib, checkpoint, tile_end,
                        dL_dcolor, grad2d, tile_grads, (float4*)nullptr);
 }
