@@ -585,7 +585,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
   const uint64_t lt = lanemask_lt();
-  uint32_t b_head = 0, b_tail = 0;
+  uint32_t n_ring = 0;      // records in the ring: one refine's survivors, from index 0 (wave-uniform)
   // finalisation (stage_batch): entry and value of this lane, float offset of the value's 16 partials in the stage
   // (stage rows 0..7 = Mx, s_r, Mxx, s_b, My, s_g, Mxy, Myy  ->  row of fp = 0, 4, 2, 6, 7, 3, 1, 5)
   const uint32_t fe = (uint32_t)lane >> 3, fp = (uint32_t)lane & 7u;
@@ -605,7 +605,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     return (uint32_t)lane < top ? list[top - 1u - lane] : list[0];
   };
   uint32_t id_ahead = idx_of(hi);
-  uint32_t np_end = 0;     // absolute ring index one past the last entry that is NOT plain
+  uint32_t np_end = 0;     // ring index one past the last entry that is NOT plain
   auto refine = [&](uint32_t top, uint32_t m) {
     bool keep = false, not_plain = false;
     float4 q0, q1, q2;
@@ -645,16 +645,17 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     const uint64_t mask = __ballot(keep);
     {
       const uint64_t npm = __ballot(not_plain);
+      np_end = 0u;
       if (npm) {
         const int top_lane = 63 - __builtin_clzll(npm);
-        np_end = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask & ((2ull << top_lane) - 1ull)));
+        np_end = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(mask & ((2ull << top_lane) - 1ull)));
       }
     }
     if (keep) {
-      const uint32_t slot = (b_tail + (uint32_t)__popcll(mask & lt)) & (kBwdQB - 1);
+      const uint32_t slot = (uint32_t)__popcll(mask & lt);
       lds.rec[slot][0] = q0; lds.rec[slot][1] = q1; lds.rec[slot][2] = q2;
     }
-    b_tail = __builtin_amdgcn_readfirstlane(b_tail + (uint32_t)__popcll(mask));   // (wave-uniform: say so)
+    n_ring = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(mask));   // (wave-uniform: say so)
     wave_lds_sync();
   };
 
@@ -722,7 +723,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             T[k] = Tn;
             acc01[k] = f32x2{ale, ale} * d01 + acc01[k];    // alpha c + (1 - alpha) acc
             acc2[k] = fmaf(ale, d2, acc2[k]);
-            any |= __builtin_amdgcn_ballot_w64(ok);
+            if (FAST) any |= __builtin_amdgcn_ballot_w64(ok);
+            else any |= __builtin_amdgcn_ballot_w64(hidx <= nc[k]) & __builtin_amdgcn_ballot_w64(pw <= 0.f) &
+                        __builtin_amdgcn_ballot_w64(alpha >= alpha_min);
           }
         }
       }
@@ -744,16 +747,17 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     constexpr bool FAST = decltype(fast_tag)::value;
     hitbits = 0;
     {
-      uint32_t slot = (b_head + base) & (kBwdQB - 1);
-      float4 a0 = lds.rec[slot][0], a1 = lds.rec[slot][1], a2 = lds.rec[slot][2];
+      // (the records are read through ONE running pointer: entry j + 1 / j + 2 at fixed offsets from it; a read
+      // beyond cnt -- at most two records past the ring, still inside this wave's LDS -- is never used)
+      const float4* rp = &lds.rec[base][0];
+      float4 a0 = rp[0], a1 = rp[1], a2 = rp[2];
       for (uint32_t j = 0; j < cnt; j += 2) {
-        slot = (b_head + base + j + 1) & (kBwdQB - 1);          // (stale beyond cnt: never processed)
-        const float4 b0 = lds.rec[slot][0], b1 = lds.rec[slot][1], b2 = lds.rec[slot][2];
+        const float4 b0 = rp[3], b1 = rp[4], b2 = rp[5];
         entry(fast_tag, j, a0, a1, a2);
         if (j + 1 >= cnt) break;
-        slot = (b_head + base + j + 2) & (kBwdQB - 1);
-        a0 = lds.rec[slot][0]; a1 = lds.rec[slot][1]; a2 = lds.rec[slot][2];
+        a0 = rp[6]; a1 = rp[7]; a2 = rp[8];
         entry(fast_tag, j + 1, b0, b1, b2);
+        rp += 6;
       }
     }
     wave_lds_sync();
@@ -764,8 +768,8 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     //   result: o0   o1   o2   o3   o4   s_op s_r  s_g  + float 8 = s_b (from lane 5)
     // private slot (always written: values or zeros), per-entry slot (deterministic mode), or atomics
     if (fe < cnt) {
-      const uint32_t slot = (b_head + base + fe) & (kBwdQB - 1);
-      const float4 q0 = lds.rec[slot][0], q1 = lds.rec[slot][1], q2 = lds.rec[slot][2];
+      const float4* fr = &lds.rec[base + fe][0];
+      const float4 q0 = fr[0], q1 = fr[1], q2 = fr[2];
       const float* sp = &lds.stage[fe][0][0];
       // (the 16-byte words are visited in a lane-rotated order: the eight lanes of an entry -- and with them all
       // 64 -- read eight different words of the 128-byte bank window at a time)
@@ -790,12 +794,13 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       out = fp >= 6u ? own : out;
       out = fp == 5u ? s_op : out;
       const uint32_t i2 = 8u + ((fp - 5u) & 7u);      // float 8 (s_b) from lane 5, the slot's padding from its neighbours
+      // (32-bit byte offsets from wave-uniform bases: a view's slots and rows are far below 4 GB)
       if (__float_as_uint(q2.z) & 16u) {
         // private slot of this (Gaussian, tile): plain stores, summed later in a fixed order by the geometry
         // backward (no atomics, deterministic)
-        float* tg = reinterpret_cast<float*>(slots + (size_t)__float_as_uint(q2.w) * kSlotVec);
-        tg[fp] = hit ? out : 0.f;
-        if (i2 < (uint32_t)kSlotFloats) tg[i2] = (hit && fp == 5u) ? own : 0.f;
+        char* tg = reinterpret_cast<char*>(slots) + __float_as_uint(q2.w) * (uint32_t)(kSlotFloats * 4);
+        *reinterpret_cast<float*>(tg + 4u * fp) = hit ? out : 0.f;
+        if (i2 < (uint32_t)kSlotFloats) *reinterpret_cast<float*>(tg + 4u * i2) = (hit && fp == 5u) ? own : 0.f;
       } else if (DET) {
         if (hit) {      // (entries that never get here keep the zeros the caller cleared the slots to)
           float* ds = reinterpret_cast<float*>(det_slots + ((size_t)l_start + (__float_as_uint(q2.y) - 1u)) * kSlotVec);
@@ -803,9 +808,10 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
           if (i2 < (uint32_t)kSlotFloats) ds[i2] = fp == 5u ? own : 0.f;
         }
       } else if (hit) {
-        float* ga = gacc + (size_t)__float_as_uint(q2.w) * kGradFloats;
-        atomicAdd(ga + fp, out);
-        if (fp == 5u) atomicAdd(ga + 8, own);
+        float* ga = reinterpret_cast<float*>(reinterpret_cast<char*>(gacc) +
+                                             __float_as_uint(q2.w) * (uint32_t)(kGradFloats * 4) + 4u * fp);
+        atomicAdd(ga, out);
+        if (fp == 5u) atomicAdd(ga + 3, own);      // float 8 = s_b
       }
     }
     wave_lds_sync();     // the staging rows are rewritten by the next batch
@@ -823,21 +829,18 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     for (uint32_t base = 0; base < m; base += kStage) {
       const uint32_t cnt = m - base < (uint32_t)kStage ? m - base : (uint32_t)kStage;
       // the batch's first entry has its highest list index (the walk runs back to front)
-      const uint32_t slot = (b_head + base) & (kBwdQB - 1);
       const uint32_t top_h =
-          __builtin_amdgcn_readfirstlane(__float_as_uint(lds.rec[slot][2].y));
+          __builtin_amdgcn_readfirstlane(__float_as_uint(lds.rec[base][2].y));
       // short form: every entry from here to the ring's tail is plain and inside every pixel's walk
-      if (b_head + base >= np_end && top_h <= nc_min) stage_batch(std::true_type{}, base, cnt);
+      if (base >= np_end && top_h <= nc_min) stage_batch(std::true_type{}, base, cnt);
       else stage_batch(std::false_type{}, base, cnt);
     }
-    b_head = __builtin_amdgcn_readfirstlane(b_head + m);
   };
 
   for (uint32_t top = hi; top > lo;) {
     const uint32_t m = top - lo < (uint32_t)kBwdBatch ? top - lo : (uint32_t)kBwdBatch;
-    refine(top, m);           // (the ring is empty here: it holds exactly one refine)
-    const uint32_t have = __builtin_amdgcn_readfirstlane(b_tail - b_head);
-    if (have != 0u) blend(have);
+    refine(top, m);           // (the ring holds exactly one refine)
+    if (n_ring != 0u) blend(n_ring);
     top -= m;
   }
 }
