@@ -560,13 +560,12 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t P = (size_t)H * W;
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  float pxf[4], pyf[4], T[4], Tfb[4], g0[4], g1[4], g2[4], acc0[4], acc1[4], acc2[4];
+  float T[4], Tfb[4], g0[4], g1[4], g2[4], acc0[4], acc1[4], acc2[4];
   uint32_t nc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int px = tx * kTile + 8 * (k & 1) + (lane & 7);
     const int py = ty * kTile + 8 * (k >> 1) + (lane >> 3);
-    pxf[k] = (float)px; pyf[k] = (float)py;
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)py * W + px : 0;
     nc[k] = inside ? n_contrib[(size_t)v * P + pix] : 0u;
@@ -582,6 +581,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       T[k] = c.x; acc0[k] = c.y; acc1[k] = c.z; acc2[k] = c.w;
     }
   }
+  const f32x2 pxy0 = f32x2{(float)(tx * kTile + (lane & 7)), (float)(ty * kTile + (lane >> 3))};   // pixel of quadrant 0
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const float alpha_max = d.alpha_max, alpha_min = d.alpha_min;
   const uint64_t lt = lanemask_lt();
@@ -678,10 +678,12 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       uint64_t any = 0ull;      // lanes with a contributing pixel, as the compares' own masks (scalar ORs)
       {
         const f32x2 c01 = f32x2{c0, c1};
+        const f32x2 d0 = f32x2{q0.x, q0.y} - pxy0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (qm & (1u << k)) {   // wave-uniform quadrant skip
-            const f32x2 dd = f32x2{q0.x, q0.y} - f32x2{pxf[k], pyf[k]};
+            // (dx, dy) to this lane's pixel of quadrant k: the entry's offset to the pixel of quadrant 0, shifted
+            const f32x2 dd = k == 0 ? d0 : d0 - f32x2{8.f * (float)(k & 1), 8.f * (float)(k >> 1)};
             const f32x2 bc = f32x2{q0.w, q1.x} * f32x2{dd.y, dd.y};        // (B dy, C dy)
             const float pw = fmaf(dd.x, fmaf(q0.z, dd.x, bc.x), dd.y * bc.y);
             const float Gv = fast_exp2(pw);
