@@ -110,6 +110,9 @@ __device__ __forceinline__ uint32_t tile_cell_mask(uint4 w, int tx, int ty) {
 
 // The 4-bit mask (bit 2 j + i) of the 2x2 cells whose first is cell (qcx, qcy) -- one 8x8 quadrant of a tile --
 // out of a pair's cell window: tile_cell_mask for the four cells a quadrant wave owns, at a third of the price
+// (`big_too` = false: the caller knows that no lane of its wave holds a large-footprint window -- a wave-uniform
+// test -- and the range arithmetic of that form is not compiled in)
+template <bool big_too = true>
 __device__ __forceinline__ uint32_t quad_cell_mask(uint4 w, int qcx, int qcy) {
   uint32_t small_mask;
   {
@@ -127,6 +130,7 @@ __device__ __forceinline__ uint32_t quad_cell_mask(uint4 w, int qcx, int qcy) {
     }
     small_mask = x_ok ? (two[0] | (two[1] << 2)) : 0u;
   }
+  if (!big_too) return small_mask;
   uint32_t big_mask;
   {
     const int i0 = cw_lo(w.x) - qcx, i1 = cw_hi(w.x) - qcx, j0 = cw_lo(w.y) - qcy, j1 = cw_hi(w.y) - qcy;

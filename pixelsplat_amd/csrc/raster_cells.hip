@@ -130,7 +130,10 @@ tiles_forward_rows_kernel(PsRasterDesc d, const float* __restrict__ records,
     id_a = id_b; id_b = id_c; win_a = win_b;
     win_b = wins[id_b];                                // the windows of the batch after the next
     id_c = load_id(scan + 192u);                       // the list indices of the one after that
-    const uint32_t mq = scan + (uint32_t)lane < l_count ? quad_cell_mask(win, qcx, qcy) : 0u;   // bit r = row r
+    // (large footprints -- over 8 cells -- are rare: their range test runs only in a batch that holds one)
+    uint32_t mq = __builtin_amdgcn_ballot_w64(win.w != 0u) != 0ull ? quad_cell_mask<true>(win, qcx, qcy)
+                                                                    : quad_cell_mask<false>(win, qcx, qcy);
+    mq = scan + (uint32_t)lane < l_count ? mq : 0u;                 // bit r = row r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool hit = (mq >> r) & 1u;

@@ -29,7 +29,7 @@ unsigned cw_tile_cell_mask(unsigned x, unsigned y, unsigned z, unsigned w, int t
   return ps::tile_cell_mask(make_uint4(x, y, z, w), tx, ty);
 }
 unsigned cw_quad_cell_mask(unsigned x, unsigned y, unsigned z, unsigned w, int qcx, int qcy) {
-  return ps::quad_cell_mask(make_uint4(x, y, z, w), qcx, qcy);
+  return ps::quad_cell_mask<true>(make_uint4(x, y, z, w), qcx, qcy);
 }
 void cw_cell_window(float px, float py, float cx, float cy, float cz, float o, float amin, unsigned* out) {
   uint4 r = ps::cell_window(px, py, cx, cy, cz, o, amin);
