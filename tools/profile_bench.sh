@@ -20,7 +20,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$
 f=$(ls $out/${tag}_prof/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" $out/${tag}_kernel_stats.csv; else
   db=$(ls $out/${tag}_prof/*.db 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_kernel_stats.py "$db" > $out/${tag}_kernel_stats.csv; fi
-pmc="$args --steps 2 --warmup 1 --no-cpu-baseline"
+# (--no-probes: the dense-scene probe launches the same kernels on ANOTHER workload; its launches would be averaged
+# into the per-launch counters -- rounds 3 - 6 had them in: tiles_backward 824 M instead of 757 M VALU instructions)
+pmc="$args --steps 2 --warmup 1 --no-cpu-baseline --no-probes"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
