@@ -122,7 +122,8 @@ typedef struct PsRasterStateLayout {
                          BEHIND it, divided by that transmittance (forward -> backward)             */
   size_t cell_windows;/* uint32[N][4]: which 4x4-pixel cells the pair can reach with alpha >= alpha_min (visible
                          entries; csrc/cell_window.h: a 64-bit mask over an 8x8 window of cells + its anchor,
-                         or a cell range) -- the tile forward's per-row cull (csrc/raster_cells.hip)     */
+                         or a cell range) -- the tile forward's per-row cull (csrc/raster_cells.hip) and the
+                         quadrant mask of the tile backward's refine (forward -> backward)          */
   size_t total;
 } PsRasterStateLayout;
 
