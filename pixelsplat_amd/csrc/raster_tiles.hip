@@ -560,7 +560,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t P = (size_t)H * W;
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  float T[4], Tfb[4], g0[4], g1[4], g2[4], acc0[4], acc1[4], acc2[4];
+  float T[4], g0[4], g1[4], g2[4], acc0[4], acc1[4], acc2[4];
   uint32_t nc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -574,11 +574,16 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     g0[k] = inside ? gp[pix] : 0.f;
     g1[k] = inside ? gp[P + pix] : 0.f;
     g2[k] = inside ? gp[2 * P + pix] : 0.f;
-    Tfb[k] = -T[k] * (bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k]);  // -T_final * (bg . dL/dC)
-    acc0[k] = acc1[k] = acc2[k] = 0.f;   // colour composited BEHIND the current entry
+    // acc = the colour composited BEHIND the current entry, over the transmittance in front of it -- the
+    // BACKGROUND included: behind a pixel's last contributor that is bg itself (T_final bg / T_final), and the
+    // recurrence acc <- alpha c + (1 - alpha) acc carries it forward.  dC/dalpha_i = T_i (c_i - acc_i) then holds
+    // the reference's second term, -T_final / (1 - alpha_i) (bg . dL/dC), already: no per-pixel register and no
+    // per-evaluation FMA for it (rounds 1 - 6a kept -T_final (bg . dL/dC) per pixel).
+    acc0[k] = bg0; acc1[k] = bg1; acc2[k] = bg2;
     if (seg == 1u && nc[k] > hi) {       // the pixel's walk continues behind the split point: start from
       const float4 c = checkpoint[((size_t)tile_global * 4 + k) * kWave + lane];   // the forward's state
-      T[k] = c.x; acc0[k] = c.y; acc1[k] = c.z; acc2[k] = c.w;
+      const float tb = T[k] / c.x;       // T_final over T at the split (> 0: the pixel passed the split)
+      T[k] = c.x; acc0[k] = fmaf(bg0, tb, c.y); acc1[k] = fmaf(bg1, tb, c.z); acc2[k] = fmaf(bg2, tb, c.w);
     }
   }
   const f32x2 pxy0 = f32x2{(float)(tx * kTile + (lane & 7)), (float)(ty * kTile + (lane >> 3))};   // pixel of quadrant 0
@@ -703,7 +708,6 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const float d2 = c2 - acc2[k];
             const f32x2 t01 = d01 * g01[k];
             float dL_dalpha = fmaf(d2, g2[k], t01.x + t01.y) * Tn;
-            dL_dalpha = fmaf(Tfb[k], rcp, dL_dalpha);       // -T_final/(1-alpha) * bg.dL/dC
             const float dch = ale * Tn;
             s_rg = f32x2{dch, dch} * g01[k] + s_rg;
             float q;                                        // opacity * G * dL/dalpha = G * dL/dG
