@@ -560,7 +560,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t P = (size_t)H * W;
   const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  float T[4], g0[4], g1[4], g2[4], acc0[4], acc1[4], acc2[4];
+  float T[4], g0[4], g1[4], g2[4], hb[4];
   uint32_t nc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -579,12 +579,16 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
     // recurrence acc <- alpha c + (1 - alpha) acc carries it forward.  dC/dalpha_i = T_i (c_i - acc_i) then holds
     // the reference's second term, -T_final / (1 - alpha_i) (bg . dL/dC), already: no per-pixel register and no
     // per-evaluation FMA for it (rounds 1 - 6a kept -T_final (bg . dL/dC) per pixel).
-    acc0[k] = bg0; acc1[k] = bg1; acc2[k] = bg2;
+    // And acc is only ever used in (c_i - acc_i) . dL/dC: the state kept per pixel is the SCALAR
+    // hb = acc . dL/dC (dL/dC is fixed per pixel), with the same recurrence hb <- hb + alpha (c . dL/dC - hb):
+    // one register instead of three per pixel, and per evaluation c . g - hb instead of a 3-vector difference.
+    float a0 = bg0, a1 = bg1, a2 = bg2;
     if (seg == 1u && nc[k] > hi) {       // the pixel's walk continues behind the split point: start from
       const float4 c = checkpoint[((size_t)tile_global * 4 + k) * kWave + lane];   // the forward's state
       const float tb = T[k] / c.x;       // T_final over T at the split (> 0: the pixel passed the split)
-      T[k] = c.x; acc0[k] = fmaf(bg0, tb, c.y); acc1[k] = fmaf(bg1, tb, c.z); acc2[k] = fmaf(bg2, tb, c.w);
+      T[k] = c.x; a0 = fmaf(bg0, tb, c.y); a1 = fmaf(bg1, tb, c.z); a2 = fmaf(bg2, tb, c.w);
     }
+    hb[k] = fmaf(a2, g2[k], fmaf(a1, g1[k], a0 * g0[k]));
   }
   const f32x2 pxy0 = f32x2{(float)(tx * kTile + (lane & 7)), (float)(ty * kTile + (lane >> 3))};   // pixel of quadrant 0
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
@@ -598,9 +602,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   // the per-pixel colour state as 2-vectors (channels 0,1 | channel 2) so that the packed
   // instructions take their operands in place (the auto-vectoriser packs the scalar form too, but
   // assembles the register pairs with ~5 v_mov per pixel and entry)
-  f32x2 acc01[4], g01[4];
+  f32x2 g01[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { acc01[k] = f32x2{acc0[k], acc1[k]}; g01[k] = f32x2{g0[k], g1[k]}; }
+  for (int k = 0; k < 4; ++k) g01[k] = f32x2{g0[k], g1[k]};
 
   // refine list entries with 1-based indices top, top-1, ..., top-m+1 (lane i takes top - i)
   // list index of this lane's entry in the batch whose first (highest) 1-based index is `top`;
@@ -704,10 +708,9 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const float ale = ok ? alpha : 0.f;            // 0 => all updates are no-ops
             const float rcp = __builtin_amdgcn_rcpf(1.f - ale);   // 1 ulp; exact 1 when ale == 0
             const float Tn = T[k] * rcp;                    // T in front of this entry
-            const f32x2 d01 = c01 - acc01[k];
-            const float d2 = c2 - acc2[k];
-            const f32x2 t01 = d01 * g01[k];
-            float dL_dalpha = fmaf(d2, g2[k], t01.x + t01.y) * Tn;
+            const f32x2 t01 = c01 * g01[k];
+            const float e = fmaf(c2, g2[k], t01.x + t01.y) - hb[k];      // (c - acc) . dL/dC
+            float dL_dalpha = e * Tn;
             const float dch = ale * Tn;
             s_rg = f32x2{dch, dch} * g01[k] + s_rg;
             float q;                                        // opacity * G * dL/dalpha = G * dL/dG
@@ -727,8 +730,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             asm("v_fmac_f32 %0, %1, %2" : "+v"(sbM.x) : "v"(dch), "v"(g2[k]));
             asm("v_fmac_f32 %0, %1, %2" : "+v"(sbM.y) : "v"(qxy.y), "v"(dd.y));
             T[k] = Tn;
-            acc01[k] = f32x2{ale, ale} * d01 + acc01[k];    // alpha c + (1 - alpha) acc
-            acc2[k] = fmaf(ale, d2, acc2[k]);
+            hb[k] = fmaf(ale, e, hb[k]);                    // (alpha c + (1 - alpha) acc) . dL/dC
             if (FAST) any |= __builtin_amdgcn_ballot_w64(ok);
             else any |= __builtin_amdgcn_ballot_w64(hidx <= nc[k]) & __builtin_amdgcn_ballot_w64(pw <= 0.f) &
                         __builtin_amdgcn_ballot_w64(alpha >= alpha_min);
