@@ -708,17 +708,15 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
             const float ale = ok ? alpha : 0.f;            // 0 => all updates are no-ops
             const float rcp = __builtin_amdgcn_rcpf(1.f - ale);   // 1 ulp; exact 1 when ale == 0
             const float Tn = T[k] * rcp;                    // T in front of this entry
-            const f32x2 t01 = c01 * g01[k];
-            const float e = fmaf(c2, g2[k], t01.x + t01.y) - hb[k];      // (c - acc) . dL/dC
-            float dL_dalpha = e * Tn;
+            const float e = fmaf(c2, g2[k], fmaf(c01.y, g01[k].y, fmaf(c01.x, g01[k].x, -hb[k])));   // (c - acc) . dL/dC
             const float dch = ale * Tn;
             s_rg = f32x2{dch, dch} * g01[k] + s_rg;
             float q;                                        // opacity * G * dL/dalpha = G * dL/dG
             if (FAST) {
-              q = ale * dL_dalpha;
+              q = dch * e;                                  // alpha dL/dalpha = (alpha T) e
               s_op += q;
             } else {
-              const float gda = ok ? Gv * dL_dalpha : 0.f;  // G * dL/dalpha
+              const float gda = ok ? Gv * (e * Tn) : 0.f;   // G * dL/dalpha
               s_op += gda;
               q = o * gda;
             }
