@@ -311,7 +311,8 @@ int ps_raster_backward(const PsRasterDesc* d, const float* means, const float* c
     if (deterministic) {      // no atomics: the per-entry slots start from zero instead
       launch_deterministic_clear(det_slots, capacity, st);
     } else if (!(d->flags & PS_FLAG_BWD_TEMP_ZEROED)) {
-      launch_clear_atomic_rows(*d, radii, rects, grad2d, st);
+      launch_clear_atomic_rows(*d, (const uint2*)(sb + L.sorted_rect), (const uint32_t*)(sb + L.sorted_idx),
+                               (const uint32_t*)(sb + L.n_vis), grad2d, st);
     }
   }
   {

@@ -346,26 +346,31 @@ color_backward_kernel(PsRasterDesc d, const float* __restrict__ means,
 // slot branch of geometry_backward_kernel above, which reads exactly these rows.  Clearing only
 // them replaces a memset of the whole [V, G, 9] array: 396 MB at configs[1], a 0.16 - 0.19 ms fill
 // kernel that took 0.11 ms out of the step even on a second stream under the forward.
+// Round 6: driven by the view's DEPTH-SORTED arrays (sorted_rect / sorted_idx hold the visible pairs only, densely:
+// 12 bytes per visible pair, coalesced) instead of radii + rects over all (view, Gaussian) pairs (4 bytes for every
+// pair and a dependent, scattered 8-byte rect for the 40 % that are visible): blocks beyond a view's n_vis leave at once.
 __global__ void __launch_bounds__(256)
-clear_atomic_rows_kernel(size_t n, int tiles_y, const int32_t* __restrict__ radii,
-                         const uint2* __restrict__ rects, float* __restrict__ grad2d) {
-  const size_t vg = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (vg >= n) return;
-  if (radii[vg] <= 0) return;           // culled pairs (60 % at configs[1]) never read their rect
-  const uint2 r = rects[vg];
+clear_atomic_rows_kernel(int G, int tiles_y, const uint2* __restrict__ sorted_rect,
+                         const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ n_vis,
+                         float* __restrict__ grad2d) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const size_t vo = (size_t)blockIdx.y * G;
+  if (i >= n_vis[blockIdx.y]) return;
+  const uint2 r = sorted_rect[vo + i];
+  const uint32_t id = sorted_idx[vo + i];
   const uint32_t area = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
   if (area <= (uint32_t)kInvSlots && tiles_y <= 16383) return;
-  float* g = grad2d + vg * kGradFloats;
+  float* g = grad2d + (vo + id) * kGradFloats;
 #pragma unroll
   for (int c = 0; c < kGradFloats; ++c) g[c] = 0.f;
 }
 
-void launch_clear_atomic_rows(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
-                              float* grad2d, hipStream_t st) {
-  const size_t n = (size_t)d.n_scenes * d.views_per_scene * d.n_gaussians;
-  if (n == 0) return;
-  hipLaunchKernelGGL(clear_atomic_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
-                     (d.height + kTile - 1) / kTile, radii, rects, grad2d);
+void launch_clear_atomic_rows(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
+                              const uint32_t* n_vis, float* grad2d, hipStream_t st) {
+  const int V = d.n_scenes * d.views_per_scene;
+  if (V == 0 || d.n_gaussians == 0) return;
+  hipLaunchKernelGGL(clear_atomic_rows_kernel, dim3((unsigned)((d.n_gaussians + 255) / 256), (unsigned)V), dim3(256),
+                     0, st, d.n_gaussians, (d.height + kTile - 1) / kTile, sorted_rect, sorted_idx, n_vis, grad2d);
 }
 
 // ---- PS_FLAG_DETERMINISTIC -------------------------------------------------------------------------

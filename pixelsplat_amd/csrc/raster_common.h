@@ -173,8 +173,8 @@ void launch_deterministic_reduce(const PsRasterDesc& d, const int32_t* radii, co
                                  uint32_t capacity, const float* det_slots, uint32_t* rank_of,
                                  float* grad2d, hipStream_t st);
 
-void launch_clear_atomic_rows(const PsRasterDesc& d, const int32_t* radii, const uint2* rects,
-                              float* grad2d, hipStream_t st);
+void launch_clear_atomic_rows(const PsRasterDesc& d, const uint2* sorted_rect, const uint32_t* sorted_idx,
+                              const uint32_t* n_vis, float* grad2d, hipStream_t st);
 void launch_preprocess_backward(const PsRasterDesc& d, const float* means, const float* cov,
                                 const float* sh, const float* view_params, const float* records,
                                 const int32_t* radii, const uint2* rects,

@@ -892,32 +892,49 @@ backward_task_order_kernel(int n_tiles, const uint32_t* __restrict__ tile_ranges
   atomicMax(&s_max, mx);
   __syncthreads();
   const uint32_t maxc = s_max;
-  auto bucket = [&](uint32_t c) -> uint32_t {   // 0 = longest
-    return 1023u - (uint32_t)(((uint64_t)c * 1023ull) / maxc);
+  // bucket 0 = longest.  Any monotone map of the walk length will do (the order inside a bucket is arbitrary but
+  // fixed): one float multiply -- the 64-bit division this replaced was ~40 instructions per task, twice
+  const float scale = 1023.f / (float)maxc;
+  auto bucket = [&](uint32_t c) -> uint32_t {
+    const uint32_t b = (uint32_t)((float)c * scale);
+    return 1023u - (b > 1023u ? 1023u : b);
   };
   if (fits) {
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) if (lo + u < hi) atomicAdd(&hist[bucket(wl[u])], 1u);
+    for (int u = 0; u < kPer; ++u) { wl[u] = bucket(wl[u]); if (lo + u < hi) atomicAdd(&hist[wl[u]], 1u); }   // (wl = bucket from here on)
   } else {
     for (int i = lo; i < hi; ++i) atomicAdd(&hist[bucket(walk(i))], 1u);
   }
   __syncthreads();
+  // exclusive scan of the 1024 bucket counts: inside each wave by DPP-free shuffles (no barrier), the 16 wave totals
+  // by the first wave, two barriers in all (the Hillis-Steele scan over LDS this replaced took twenty)
   const uint32_t hsum = hist[threadIdx.x];
-  part[threadIdx.x] = hsum;
-  __syncthreads();
   uint32_t hx = hsum;
-  for (int off = 1; off < 1024; off <<= 1) {
-    const uint32_t y = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    hx += y; part[threadIdx.x] = hx;
-    __syncthreads();
+  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(hx, off);
+    if (ln >= off) hx += y;
   }
-  hist[threadIdx.x] = hx - hsum;   // exclusive start of the bucket
+  if (ln == 63) part[wv] = hx;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t t = threadIdx.x < 16 ? part[threadIdx.x] : 0u;
+    uint32_t tx = t;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t y = __shfl_up(tx, off);
+      if ((int)threadIdx.x >= off) tx += y;
+    }
+    if (threadIdx.x < 16) part[threadIdx.x] = tx - t;       // exclusive start of the wave's buckets
+  }
+  __syncthreads();
+  hist[threadIdx.x] = part[wv] + hx - hsum;   // exclusive start of the bucket
   __syncthreads();
   if (fits) {
 #pragma unroll
     for (int u = 0; u < kPer; ++u)
-      if (lo + u < hi) task_order[atomicAdd(&hist[bucket(wl[u])], 1u)] = (uint32_t)(lo + u);
+      if (lo + u < hi) task_order[atomicAdd(&hist[wl[u]], 1u)] = (uint32_t)(lo + u);
   } else {
     for (int i = lo; i < hi; ++i) task_order[atomicAdd(&hist[bucket(walk(i))], 1u)] = (uint32_t)i;
   }
