@@ -104,7 +104,8 @@ typedef struct PsRasterDesc {
 /* byte offsets of the arrays inside the `state` buffer (for tests / debugging).
  * V = n_scenes*views_per_scene, N = V*G, P = H*W, T = tiles per view. */
 typedef struct PsRasterStateLayout {
-  size_t records;     /* float[N][12]: px,py,conx,cony | conz,opacity,depth,packed small-rect origin (u32) | r,g,b,clamp bits */
+  size_t records;     /* float[N][16], one 64-byte line per pair: px,py,conx,cony | conz,opacity,depth,packed small-rect
+                         origin (u32) | r,g,b,clamp bits | the pair's cell window (4 x u32, see cell_windows)      */
   size_t rects;       /* uint16[N][4]: tile rect xmin,ymin,xmax,ymax                   */
   size_t sorted_idx;  /* uint32[N]: per view, Gaussian ids in (depth, id) order; first n_vis valid */
   size_t sorted_rect; /* uint16[N][4]: rects permuted into sorted order                */
@@ -120,7 +121,8 @@ typedef struct PsRasterStateLayout {
   size_t checkpoint;  /* float[V][T][4][64][4]: per pixel (quadrant, lane) of a tile whose list is split in two
                          for the backward: transmittance after the list's first half and the colour composited
                          BEHIND it, divided by that transmittance (forward -> backward)             */
-  size_t cell_windows;/* uint32[N][4]: which 4x4-pixel cells the pair can reach with alpha >= alpha_min (visible
+  size_t cell_windows;/* = records + 48: the fourth 16-byte word of every record line, STRIDE 64 bytes (version 7; a
+                         separate array in version 6).  uint32[4]: which 4x4-pixel cells the pair can reach with alpha >= alpha_min (visible
                          entries; csrc/cell_window.h: a 64-bit mask over an 8x8 window of cells + its anchor,
                          or a cell range) -- the tile forward's per-row cull (csrc/raster_cells.hip) and the
                          quadrant mask of the tile backward's refine (forward -> backward)          */
@@ -552,9 +554,9 @@ const char* ps_build_info(void);
 /* Layout version of the descriptor structs of this header (PsRasterDesc, PsEpipolarDesc, ...): bumped
  * whenever a struct grows or a field changes meaning.  A host built against an older header would hand
  * the library shorter structs (PsEpipolarDesc grew by tail_pad_in / tail_pad_out in version 4; PsRasterStateLayout by
- * cell_windows in version 6): check
+ * cell_windows in version 6, interleaved with the records in version 7): check
  * ps_abi_version() == PS_ABI_VERSION once after loading (pixelsplat_amd/_lib.py does). */
-#define PS_ABI_VERSION 6
+#define PS_ABI_VERSION 7
 int ps_abi_version(void);
 
 #ifdef __cplusplus

@@ -83,7 +83,7 @@ EXPORTS = [
     "ps_profile_enable", "ps_profile_group_count", "ps_profile_group_name", "ps_profile_collect",
     "ps_abi_version",
 ]
-PS_ABI_VERSION = 6      # include/pixelsplat_hip.h
+PS_ABI_VERSION = 7      # include/pixelsplat_hip.h
 
 _lib = None
 

@@ -82,7 +82,7 @@ tiles_forward_rows_kernel(PsRasterDesc d, const float* __restrict__ records,
   const int v = tile_global / tiles, t = tile_global % tiles;
   const int tx = t % gxn, ty = t / gxn;
   const float* recs = records + (size_t)v * G * kRecFloats;
-  const uint4* wins = cell_windows + (size_t)v * G;
+  const uint4* wins = cell_windows + (size_t)v * G * (kRecFloats / 4);     // (one per record line)
   uint32_t l_start = tile_ranges[2 * (size_t)tile_global];
   uint32_t l_count = tile_ranges[2 * (size_t)tile_global + 1];
   if (l_start > capacity) l_start = capacity;                       // overflowed step: stay in
@@ -122,13 +122,13 @@ tiles_forward_rows_kernel(PsRasterDesc d, const float* __restrict__ records,
   uint4 win_a = make_uint4(0u, 0u, 0u, 0u), win_b = win_a;
   if (l_count > 0) {
     id_a = load_id(0u); id_b = load_id(64u); id_c = load_id(128u);
-    win_a = wins[id_a]; win_b = wins[id_b];
+    win_a = wins[(size_t)id_a * (kRecFloats / 4)]; win_b = wins[(size_t)id_b * (kRecFloats / 4)];
   }
   uint32_t scan = 0;                  // next list entry to scan (a multiple of 64)
   auto scan_batch = [&]() {
     const uint32_t id = id_a; const uint4 win = win_a;
     id_a = id_b; id_b = id_c; win_a = win_b;
-    win_b = wins[id_b];                                // the windows of the batch after the next
+    win_b = wins[(size_t)id_b * (kRecFloats / 4)];     // the windows of the batch after the next
     id_c = load_id(scan + 192u);                       // the list indices of the one after that
     // (large footprints -- over 8 cells -- are rare: their range test runs only in a batch that holds one)
     uint32_t mq = __builtin_amdgcn_ballot_w64(win.w != 0u) != 0ull ? quad_cell_mask<true>(win, qcx, qcy)

@@ -11,7 +11,11 @@ namespace ps {
 constexpr int kWave = 64;
 constexpr int kTile = 16;               // 16x16 pixel tiles (bin parity with the reference)
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
-constexpr int kRecFloats = 12;          // one 48-byte record per (view, gaussian)
+// One 64-byte LINE per (view, Gaussian): the 48-byte record + the pair's 16-byte cell window (cell_window.h) behind
+// it.  Round 6: the tile kernels gather both for the same list entries -- as two arrays that was two memory lines per
+// entry (a 48-byte record straddling sectors and a 16-byte window using a quarter of its own), now it is one.
+constexpr int kRecFloats = 16;
+constexpr int kRecWindow = 3;           // the window is the record's fourth 16-byte word
 constexpr int kGradFloats = 9;          // dxy(2) dconic(3) dopacity(1) drgb(3)
 constexpr int kSlotFloats = 12;         // per-(tile, entry) gradient slot: 9 used, 16-byte aligned
 constexpr int kInvSlots = 4;            // Gaussians touching <= 4 tiles use slots, larger ones atomics
@@ -117,7 +121,7 @@ inline PsRasterStateLayout make_state_layout(const PsRasterDesc& d) {
   s.tile_order = o; o = align_up(o + (size_t)m.V * m.tiles * 4);
   s.clamp_bits = o; o = align_up(o + m.N);
   s.checkpoint = o; o = align_up(o + (size_t)m.V * m.tiles * kTile * kTile * 16);
-  s.cell_windows = o; o = align_up(o + m.N * 16);
+  s.cell_windows = s.records + kRecWindow * 16;   // interleaved with the records: stride kRecFloats * 4 bytes
   s.total = o;
   return s;
 }

@@ -168,7 +168,7 @@ geometry_forward_kernel(PsRasterDesc d, const float* __restrict__ means,
       float4* r = reinterpret_cast<float4*>(records + vg * kRecFloats);
       r[0] = make_float4(o.px, o.py, o.con_x, o.con_y);
       r[1] = make_float4(o.con_z, opac, o.tvz, __uint_as_float(packed_small_rect(o, gy)));
-      cell_windows[vg] = cell_window(o.px, o.py, o.con_x, o.con_y, o.con_z, opac, d.alpha_min);
+      cell_windows[vg * (kRecFloats / 4)] = cell_window(o.px, o.py, o.con_x, o.con_y, o.con_z, opac, d.alpha_min);
       if (colors != nullptr) {   // colors_precomp: verbatim, no clamp
         const float* cp = colors + vg * 3;
         r[2] = make_float4(cp[0], cp[1], cp[2], __uint_as_float(0u));
@@ -348,7 +348,7 @@ preprocess_fused_kernel(PsRasterDesc d, const float* __restrict__ means,
   r[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
   clamp_out[vg] = (uint8_t)clamp_bits;   // compact copy for the backward
   // which 4x4 cells the pair can reach (the tile forward's cull, cell_window.h)
-  cell_windows[vg] = cell_window(o.px, o.py, o.con_x, o.con_y, o.con_z, opac, d.alpha_min);
+  cell_windows[vg * (kRecFloats / 4)] = cell_window(o.px, o.py, o.con_x, o.con_y, o.con_z, opac, d.alpha_min);
 }
 
 void launch_preprocess_forward(const PsRasterDesc& d, const float* means, const float* cov,

@@ -519,7 +519,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   const uint32_t tx = t % gx, ty = t / gx;
   const size_t vo = (size_t)v * G;
   const float* recs = records + vo * kRecFloats;
-  const uint4* wins = cell_windows + vo;
+  const uint4* wins = cell_windows + vo * (kRecFloats / 4);     // (one per record line)
   float* gacc = grad2d + vo * kGradFloats;
   uint32_t l_start = tile_ranges[2 * (size_t)tile_global];
   if (l_start > capacity) l_start = capacity;
@@ -624,7 +624,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
       const uint32_t id = id_now;
       const float4* r = reinterpret_cast<const float4*>(recs + (size_t)id * kRecFloats);
       const float4 r0 = r[0], r1 = r[1], r2 = r[2];   // {px,py,cx,cy} {cz,o,depth,radius} {r,g,b,-}
-      const uint4 win = wins[id];
+      const uint4 win = wins[(size_t)id * (kRecFloats / 4)];
       const float A = -0.5f * kLog2e * r0.z, B = -kLog2e * r0.w, Cq = -0.5f * kLog2e * r1.x;
       // which quadrants the entry can reach with alpha >= alpha_min: read off the pair's cell window (the
       // preprocess computed it once per pair, cell_window.h; rounds 2 - 5 minimised the quadratic form over

@@ -340,8 +340,10 @@ def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
     def view(off, nbytes, dtype, shape):
         return state[off:off + nbytes].view(dtype).reshape(shape)
 
+    # one 64-byte line per pair: the 48-byte record + its 16-byte cell window (csrc/raster_common.h: kRecFloats)
+    lines = view(lay.records, N * 64, torch.float32, (V, G, 16))
     return dict(
-        records=view(lay.records, N * 48, torch.float32, (V, G, 12)),
+        records=lines[..., :12],
         rects=view(lay.rects, N * 8, torch.int16, (V, G, 4)),
         sorted_idx=view(lay.sorted_idx, N * 4, torch.int32, (V, G)),
         sorted_rect=view(lay.sorted_rect, N * 8, torch.int16, (V, G, 4)),
@@ -356,7 +358,7 @@ def state_views(cfg: RasterConfig, state: Tensor, lay) -> dict:
         checkpoint=view(lay.checkpoint, V * tiles * 256 * 16, torch.float32, (V, tiles, 4, 64, 4)),
         # which 4x4-pixel cells a visible pair can reach with alpha >= alpha_min (csrc/cell_window.h): small
         # window = (mask lo, mask hi, anchor cx | cy << 16, 0), large footprint = (cx0 | cx1 << 16, cy0 | cy1 << 16, -, 1)
-        cell_windows=view(lay.cell_windows, N * 16, torch.int32, (V, G, 4)),
+        cell_windows=lines.view(torch.int32)[..., 12:16],
     )
 
 
