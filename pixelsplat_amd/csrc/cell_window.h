@@ -1,7 +1,8 @@
 // Which 4x4-pixel cells can a projected Gaussian reach with alpha >= alpha_min?  (round 6)
 //
-// Producer (raster_preprocess.hip, once per visible (view, Gaussian) pair) and consumer
-// (raster_cells.hip, once per tile-list entry) of the 16-byte "cell window" of a pair:
+// Producer (raster_preprocess.hip, once per visible (view, Gaussian) pair) and consumers (raster_cells.hip: the
+// rows forward's per-cell cull; raster_tiles.hip: the quadrant mask of the tile backward's refine -- once per
+// tile-list entry each) of the 16-byte "cell window" of a pair, the fourth 16-byte word of the pair's record line:
 //   small  x, y = 64-bit mask of an 8x8 window of cells (bit 8 * wy + wx), z = anchor cell (ax | ay << 16,
 //          signed 16-bit each): bit set <=> the ellipse {alpha >= alpha_min} meets the box of pixel
 //          centres of cell (ax + wx, ay + wy); w = 0

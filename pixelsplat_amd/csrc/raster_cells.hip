@@ -11,7 +11,7 @@
 // One wave per tile QUADRANT (the four waves of a block = one tile), one pixel per lane, row r = cell r of
 // the quadrant.  The wave runs a two-stage pipeline over the tile's bin, all of it in LDS:
 //   scan    64 list entries at a time, one per lane: the pair's 16-byte cell window (cell_window.h; the
-//           preprocess wrote it) -> the 4-bit mask of the quadrant's cells -> four wave64 ballots append
+//           preprocess wrote it into the pair's 64-byte record line, which the blend's record gather then finds fetched) -> the 4-bit mask of the quadrant's cells -> four wave64 ballots append
 //           (Gaussian id, list position) to the four rows' RINGS in list order (rank by mbcnt; the ring
 //           cursors are wave-uniform scalars).  The list indices run two batches ahead of the scan and the
 //           windows one.

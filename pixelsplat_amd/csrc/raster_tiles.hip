@@ -1,23 +1,32 @@
-// Tile kernels.  A 16x16 tile is four 8x8 QUADRANTS; a wave64 owns kFwdQW of them in the forward
-// (2: two waves per tile) and all four in the backward, one pixel per lane and quadrant -- pixel
-// k of lane l sits in quadrant k at (l & 7, l >> 3).  Each staged entry carries a 4-bit mask of the
-// quadrants its alpha >= 1/255 ellipse can reach, so the per-entry work is skipped per quadrant with
-// wave-uniform (scalar) branches.  There is no duplicated (tile, Gaussian) key list and no global
-// sort over it.  Per tile a wave runs a two-stage, LDS-resident pipeline over the tile's bin:
+// Tile kernels on 8x8 QUADRANTS.  A 16x16 tile is four quadrants; one pixel per lane and quadrant -- pixel k of
+// lane l sits in quadrant k at (l & 7, l >> 3).  Two kernels live here:
 //
-//   list     the tile's bin (raster_bins.hip): Gaussian ids in (depth, id) order, exactly
-//            the reference's per-tile range of its sorted point list; the
-//            1-based position in it is the "contributor" index n_contrib refers to.
-//   refine   64 list entries at a time, one per lane: gather the 48-byte record and test
-//            the alpha >= 1/255 ellipse against the wave's quadrants (exact conservative
-//            bound: the minimum of the quadratic form over the box).  Entries that cannot
-//            reach 1/255 on any of its pixels are dropped -- every pixel would have
-//            skipped them anyway (A.3), so results are unchanged -- survivors go to ring B
-//            with exp2-scaled conic coefficients.
-//   blend    64 ring-B entries at a time, broadcast from LDS, branch-free per-pixel update.
+//   tiles_backward_kernel   the shipped backward: one wave walks a tile's bin back to front (two tasks per tile),
+//                           all four quadrants per wave.  Its refine reads an entry's 4-bit quadrant mask off the
+//                           pair's cell window (cell_window.h: written once per pair by the preprocess), its per-pixel
+//                           state is T, dL/dC and the scalar (colour behind, background included) . dL/dC, its nine
+//                           per-entry sums are finished through LDS by eight lanes per entry (round 6).
+//   tiles_forward_kernel    the round-2..5 forward (two waves per tile, kFwdQW quadrants each), kept as the A/B
+//                           reference of the shipped 4x4-cell forward (raster_cells.hip; PS_FORWARD_QUADRANTS=1 selects
+//                           this one, tools/ab_cells.sh): its refine still minimises the quadratic form over each
+//                           quadrant's box per list entry (exact conservative bound).
 //
-// What was tried on these two kernels and what an instruction costs here: DESIGN.md 4 / 4a,
-// profiles/r2_tiles_variants_ab.txt, profiles/r3_{issue_model,forward_forms_ab,forward_split_ab}.txt.
+// Common to both: every staged entry carries the mask of the quadrants its alpha >= 1/255 ellipse can reach, so the
+// per-entry work is skipped per quadrant with wave-uniform (scalar) branches; an entry that reaches no quadrant is
+// dropped -- every pixel would have skipped it anyway, so results are unchanged.  There is no
+// duplicated (tile, Gaussian) key list and no global sort over it.  Per tile a wave runs a two-stage, LDS-resident
+// pipeline over the tile's bin:
+//
+//   list     the tile's bin (raster_bins.hip): Gaussian ids in (depth, id) order, exactly the reference's per-tile
+//            range of its sorted point list; the 1-based position in it is the "contributor" index
+//            n_contrib refers to.
+//   refine   64 list entries at a time, one per lane: gather the pair's 64-byte line (record + cell window), decide
+//            the quadrant mask, compact the survivors into a ring in LDS with exp2-scaled conic coefficients.
+//   blend    ring entries broadcast from LDS, branch-free per-pixel update.
+//
+// What was tried on these two kernels and what an instruction costs here: DESIGN.md 4 / 4a / 15,
+// profiles/r2_tiles_variants_ab.txt, profiles/r3_{issue_model,forward_forms_ab,forward_split_ab}.txt,
+// profiles/r6_ab_backward_lds_reduce.txt.
 //
 // Replaces renderCUDA fwd/bwd of the external rasterizer (call site
 // /root/reference/src/model/decoder/cuda_splatting.py:117-124).
@@ -76,37 +85,11 @@ __device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
 // v_exp_f32: 2^x
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Conservative test: can alpha = opacity * exp(power) reach alpha_min on the box of pixel
-// centres [x0,x0+15] x [y0,y0+15]?  With A,B,C the log2-scaled coefficients
-// (power*log2e = A dx^2 + B dx dy + C dy^2, d = centre - pixel), Q = -(power*log2e) is a
-// convex quadratic for a positive-definite conic; its minimum over the box is 0 if the
-// centre is inside, else it lies on the (at most two) box edges facing the centre.
-__device__ __forceinline__ bool may_contribute(float gx, float gy, float A, float B, float Cq,
-                                               float opacity, float alpha_min, float x0,
-                                               float y0) {
-  const float tau = __log2f(opacity / alpha_min);   // need Q <= tau somewhere
-  if (!(tau >= 0.f)) return false;                  // opacity < alpha_min (or NaN): never
-  const float det = 4.f * A * Cq - B * B;
-  if (!(A < 0.f && Cq < 0.f && det > 0.f)) return true;  // not positive definite: keep
-  const float dxlo = gx - (x0 + 15.f), dxhi = gx - x0;   // range of dx over the box
-  const float dylo = gy - (y0 + 15.f), dyhi = gy - y0;
-  const float ex = dxlo > 0.f ? dxlo : (dxhi < 0.f ? dxhi : 0.f);  // nearest-edge offsets
-  const float ey = dylo > 0.f ? dylo : (dyhi < 0.f ? dyhi : 0.f);
-  if (ex == 0.f && ey == 0.f) return true;          // centre inside the box
-  float qmin = 3.0e38f;
-  if (ex != 0.f) {                                  // vertical edge dx = ex
-    const float dy = fminf(dyhi, fmaxf(dylo, -B * ex / (2.f * Cq)));
-    qmin = fminf(qmin, -(A * ex * ex + B * ex * dy + Cq * dy * dy));
-  }
-  if (ey != 0.f) {                                  // horizontal edge dy = ey
-    const float dx = fminf(dxhi, fmaxf(dxlo, -B * ey / (2.f * A)));
-    qmin = fminf(qmin, -(A * dx * dx + B * dx * ey + Cq * ey * ey));
-  }
-  // margin covers fp32 rounding of this bound and of the per-pixel power evaluation
-  return !(qmin > tau + 1e-4f * fabsf(tau) + 1e-3f);
-}
-
-// same bound on an (8+1)x(8+1) box of pixel centres [x0,x0+7] x [y0,y0+7] given tau
+// Conservative test of the round-2..5 forward: can alpha = opacity * exp(power) reach alpha_min on the box of pixel
+// centres [x0,x0+7] x [y0,y0+7], given tau = log2(opacity / alpha_min)?  With A,B,C the log2-scaled coefficients
+// (power*log2e = A dx^2 + B dx dy + C dy^2, d = centre - pixel), Q = -(power*log2e) is a convex quadratic for a
+// positive-definite conic; its minimum over the box is 0 if the centre is inside, else it lies on the (at most two)
+// box edges facing the centre.  The margin covers fp32 rounding of this bound and of the per-pixel power evaluation.
 __device__ __forceinline__ bool quad_may_contribute(float gx, float gy, float A, float B,
                                                     float Cq, float tau, float x0, float y0) {
   const float dxlo = gx - (x0 + 7.f), dxhi = gx - x0;
@@ -126,23 +109,6 @@ __device__ __forceinline__ bool quad_may_contribute(float gx, float gy, float A,
   return !(qmin > tau + 1e-4f * fabsf(tau) + 1e-3f);
 }
 
-// 4-bit mask of the tile's 8x8 quadrants (bit k: x half = k & 1, y half = k >> 1) that the
-// entry can touch with alpha >= alpha_min; 0 = drop the entry.
-__device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, float B, float Cq,
-                                                  float opacity, float alpha_min, float x0,
-                                                  float y0) {
-  const float tau = __log2f(opacity / alpha_min);
-  if (!(tau >= 0.f)) return 0u;
-  const float det = 4.f * A * Cq - B * B;
-  if (!(A < 0.f && Cq < 0.f && det > 0.f)) return 0xFu;  // not positive definite: keep all
-  uint32_t m = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (quad_may_contribute(gx, gy, A, B, Cq, tau, x0 + 8.f * (k & 1), y0 + 8.f * (k >> 1)))
-      m |= 1u << k;
-  return m;
-}
-
 // Is an entry "plain"?  Its conic is positive definite with a condition number far from fp32 round-off
 // (so `power > 0` cannot happen for any pixel: the true power is <= -lambda_min |d|^2 and its fp32
 // evaluation is off by < 4e-7 lambda_max |d|^2) and its opacity is below the alpha_max clamp.  Such an
@@ -160,7 +126,8 @@ __device__ __forceinline__ bool entry_is_plain(float gx, float gy, float A, floa
          opacity >= 0.f;
 }
 
-// the same for the QW quadrants first .. first + QW - 1 of the tile only (bit k: quadrant first + k)
+// the mask of the QW quadrants first .. first + QW - 1 of a tile an entry can reach (bit k: quadrant first + k);
+// 0 = drop the entry
 template <int QW>
 __device__ __forceinline__ uint32_t quadrant_mask_part(float gx, float gy, float A, float B,
                                                        float Cq, float opacity, float alpha_min,
@@ -669,7 +636,7 @@ tiles_backward_kernel(PsRasterDesc d, const float* __restrict__ records,
   };
 
   uint32_t hitbits = 0;   // bit j: entry j of the finalisation batch contributed (wave-uniform)
-  // one ring entry: the pixels' updates, the nine wave sums down to 8-lane partials, staged in LDS.
+  // one ring entry: the pixels' updates, the nine wave sums down to 16-lane partials, staged in LDS.
   // FAST (decided per blend call, see blend()): every entry of the call is plain (entry_is_plain:
   // no sign test of the power, no alpha_max clamp) and lies at or before EVERY pixel's last
   // contributor (no `hidx <= n_contrib` test), and alpha = opacity * G lets q = opacity * G * dL/dalpha
