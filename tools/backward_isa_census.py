@@ -19,7 +19,8 @@ print("'evaluation block' = a basic block that contains the v_exp_f32 of one qua
 print("x 4 quadrants = 16 of them; the first quadrant of an entry also initialises the entry's accumulators).")
 meta = re.search(r'\.amdhsa_kernel _ZN2ps21tiles_backward_kernelILb0E.*?\.end_amdhsa_kernel', txt, re.S).group(0)
 for key in ('next_free_vgpr', 'next_free_sgpr', 'group_segment_fixed_size', 'private_segment_fixed_size'):
-    print(f"  {key:28s} {re.search(r'.amdhsa_%s (\d+)' % key, meta).group(1)}")
+    val = re.search(r'.amdhsa_%s (\d+)' % key, meta).group(1)
+    print(f"  {key:28s} {val}")
 blocks, cur = [], []
 for line in body:
     s = line.strip()
